@@ -1,0 +1,350 @@
+// api.cpp — the extern "C" surface of libdsdiff.so (see include/dsdiff.h).
+#include <cstring>
+#include <vector>
+
+#include "net.h"
+
+using namespace dsd;
+
+static thread_local std::string g_err;
+
+#define DSD_TRY try {
+#define DSD_CATCH                          \
+    }                                      \
+    catch (const std::exception& e) {      \
+        g_err = e.what();                  \
+        return -1;                         \
+    }                                      \
+    catch (...) {                          \
+        g_err = "unknown error";           \
+        return -1;                         \
+    }                                      \
+    return 0;
+
+namespace {
+
+void ensure_buf(float** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes) return;
+    if (*p) {
+        DSD_HIP(hipDeviceSynchronize());
+        DSD_HIP(hipFree(*p));
+        *p = nullptr;
+        *cap = 0;
+    }
+    DSD_HIP(hipMalloc((void**)p, bytes));
+    *cap = bytes;
+}
+
+// temp device buffer for the dsd_op_* test entry points
+struct Tmp {
+    void* p = nullptr;
+    explicit Tmp(size_t bytes) { DSD_HIP(hipMalloc(&p, bytes ? bytes : 256)); }
+    ~Tmp() {
+        if (p) {
+            hipDeviceSynchronize();
+            hipFree(p);
+        }
+    }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+void set_device(int device) { DSD_HIP(hipSetDevice(device)); }
+
+void bind_planes(dsd_handle* h, const float* x, int C, int H, int W, hipStream_t s) {
+    const int64_t hw = (int64_t)H * W;
+    DSD_CHECK(C == 2 || C == 4, "x must have 2 or 4 channels (noise + 1 or 3 conditions), got %d", C);
+    h->io.plane[0] = x;
+    h->io.plane[1] = x + hw;
+    h->io.plane_bs[0] = h->io.plane_bs[1] = (int64_t)C * hw;
+    if (C == 2) {  // model.py:654-658: al = l = zeros_like(n)
+        ensure_buf(&h->zplane, &h->zplane_cap, (size_t)hw * sizeof(float));
+        DSD_HIP(hipMemsetAsync(h->zplane, 0, (size_t)hw * sizeof(float), s));
+        h->io.plane[2] = h->io.plane[3] = h->zplane;
+        h->io.plane_bs[2] = h->io.plane_bs[3] = 0;
+    } else {       // model.py:660-663
+        h->io.plane[2] = x + 2 * hw;
+        h->io.plane[3] = x + 3 * hw;
+        h->io.plane_bs[2] = h->io.plane_bs[3] = (int64_t)C * hw;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* dsd_last_error(void) { return g_err.c_str(); }
+
+int dsd_device_info(int device, char* name, int name_len, int* n_cu, int64_t* hbm_bytes) {
+    DSD_TRY
+    int cnt = 0;
+    DSD_HIP(hipGetDeviceCount(&cnt));
+    DSD_CHECK(device >= 0 && device < cnt, "device %d not present (%d visible)", device, cnt);
+    hipDeviceProp_t prop;
+    DSD_HIP(hipGetDeviceProperties(&prop, device));
+    DSD_CHECK(std::strncmp(prop.gcnArchName, "gfx950", 6) == 0, "device %d is %s; libdsdiff is built for gfx950 only", device,
+              prop.gcnArchName);
+    if (name && name_len > 0) {
+        std::strncpy(name, prop.name, name_len - 1);
+        name[name_len - 1] = 0;
+    }
+    if (n_cu) *n_cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    DSD_CATCH
+}
+
+int dsd_create(const dsd_config* cfg, int device, dsd_handle** out) {
+    DSD_TRY
+    DSD_CHECK(cfg && out, "null argument");
+    set_device(device);
+    auto* h = new dsd_handle();
+    h->device = device;
+    h->cfg = *cfg;
+    try {
+        net_declare_params(h);
+    } catch (...) {
+        net_free(h);
+        delete h;
+        throw;
+    }
+    *out = h;
+    DSD_CATCH
+}
+
+int dsd_block_create(int kind, const int32_t* iargs, int n_iargs, int device, dsd_handle** out) {
+    DSD_TRY
+    DSD_CHECK(out && (iargs || n_iargs == 0), "null argument");
+    set_device(device);
+    auto* h = new dsd_handle();
+    h->device = device;
+    h->is_block = true;
+    h->block_kind = kind;
+    h->iargs.assign(iargs, iargs + n_iargs);
+    h->cfg.use_new_attention_order = 1;
+    try {
+        net_declare_params(h);
+    } catch (...) {
+        net_free(h);
+        delete h;
+        throw;
+    }
+    *out = h;
+    DSD_CATCH
+}
+
+void dsd_destroy(dsd_handle* h) {
+    if (!h) return;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    net_free(h);
+    delete h;
+}
+
+int dsd_param_count(dsd_handle* h) { return h ? (int)h->params.size() : -1; }
+
+int dsd_param_info(dsd_handle* h, int idx, const char** name, int64_t shape[4], int* ndim) {
+    DSD_TRY
+    DSD_CHECK(h && idx >= 0 && idx < (int)h->params.size(), "parameter index out of range");
+    const Param& p = h->params[idx];
+    if (name) *name = p.name.c_str();
+    if (ndim) *ndim = (int)p.shape.size();
+    if (shape)
+        for (size_t i = 0; i < 4; ++i) shape[i] = i < p.shape.size() ? p.shape[i] : 1;
+    DSD_CATCH
+}
+
+int dsd_set_param(dsd_handle* h, const char* name, const float* src, const int64_t* shape, int ndim, int src_is_device,
+                  void* stream) {
+    DSD_TRY
+    DSD_CHECK(h && name && src && shape, "null argument");
+    set_device(h->device);
+    net_set_param(h, name, src, shape, ndim, src_is_device, (hipStream_t)stream);
+    DSD_CATCH
+}
+
+int dsd_params_ready(dsd_handle* h) {
+    DSD_TRY
+    DSD_CHECK(h, "null handle");
+    for (const auto& p : h->params) DSD_CHECK(p.set, "parameter '%s' has not been set", p.name.c_str());
+    DSD_CATCH
+}
+
+int dsd_plan(dsd_handle* h, int B, int C, int H, int W) {
+    DSD_TRY
+    DSD_CHECK(h && !h->is_block, "dsd_plan needs a model handle");
+    set_device(h->device);
+    DSD_CHECK(C == 2 || C == 4, "x must have 2 or 4 channels, got %d", C);
+    net_plan(h, B, C, H, W, C == 2, 0, 0, 0);
+    DSD_CATCH
+}
+
+int64_t dsd_workspace_bytes(dsd_handle* h) { return h && h->plan.valid ? (int64_t)h->plan.arena_bytes : -1; }
+int dsd_plan_launches(dsd_handle* h) { return h && h->plan.valid ? h->plan.launches : -1; }
+double dsd_plan_flops(dsd_handle* h) { return h && h->plan.valid ? h->plan.flops : -1.0; }
+
+int dsd_forward(dsd_handle* h, const float* x, const void* t, int t_is_float, int B, int C, int H, int W, float* out,
+                float* const* feats, void* stream) {
+    DSD_TRY
+    DSD_CHECK(h && !h->is_block && x && t && out, "null argument");
+    set_device(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    net_plan(h, B, C, H, W, C == 2, feats != nullptr, 0, 0);
+    bind_planes(h, x, C, H, W, s);
+    h->io.t = t;
+    h->io.t_is_float = t_is_float;
+    h->io.out = out;
+    h->io.feats = feats;
+    net_run(h, s);
+    DSD_CATCH
+}
+
+int dsd_block_forward(dsd_handle* h, const float* x, int B, int C, int H, int W, const float* aux, int aux_len,
+                      const float* aux2, int aux_len2, float* out, void* stream) {
+    DSD_TRY
+    DSD_CHECK(h && h->is_block && x && out, "null argument / not a block handle");
+    set_device(h->device);
+    net_plan(h, B, C, H, W, 0, 0, aux ? aux_len : 0, aux2 ? aux_len2 : 0);
+    h->io.x_nchw = x;
+    h->io.aux = aux;
+    h->io.aux2 = aux2;
+    h->io.out = out;
+    net_run(h, (hipStream_t)stream);
+    DSD_CATCH
+}
+
+static StepCoef step_coef(const dsd_schedule* sc, int k) {
+    StepCoef c{};
+    for (int j = 0; j < DSD_NCOEF; ++j) c.c[j] = sc->coef[(size_t)k * DSD_NCOEF + j];
+    c.mode = sc->mode; c.pred = sc->pred; c.learned_range = sc->learned_range; c.clip = sc->clip_denoised;
+    c.nonzero = sc->nonzero ? sc->nonzero[k] : 1;
+    c.eta = sc->eta;
+    return c;
+}
+
+static void check_schedule(const dsd_schedule* sc) {
+    DSD_CHECK(sc && sc->coef && sc->t_model && sc->steps >= 1, "bad schedule");
+    DSD_CHECK(sc->mode >= DSD_MODE_A_DDPM && sc->mode <= DSD_MODE_B_DDIM, "unknown sampler mode %d", sc->mode);
+    DSD_CHECK(sc->pred >= DSD_PRED_EPS && sc->pred <= DSD_PRED_V, "unknown prediction type %d", sc->pred);
+    DSD_CHECK(!(sc->learned_range && sc->mode >= DSD_MODE_B_DDPM), "learned-range variance exists only in the guided-diffusion family");
+}
+
+int dsd_sample(dsd_handle* h, const dsd_schedule* sc, const float* cond, int Cc, float* x, const float* noise,
+               uint64_t philox_seed, int B, int H, int W, int first_step, int n_steps, void* stream) {
+    DSD_TRY
+    DSD_CHECK(h && !h->is_block && cond && x, "null argument");
+    check_schedule(sc);
+    DSD_CHECK(Cc == 1 || Cc == 3, "cond must have 1 or 3 channels, got %d", Cc);
+    const int out_ch = h->cfg.out_channels;
+    DSD_CHECK(out_ch == (sc->learned_range ? 2 : 1), "model has %d output channels but the schedule expects %d", out_ch,
+              sc->learned_range ? 2 : 1);
+    set_device(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t hw = (int64_t)H * W;
+    net_plan(h, B, Cc + 1, H, W, Cc == 1, 0, 0, 0);
+    ensure_buf(&h->tbuf, &h->tbuf_cap, (size_t)B * sizeof(float));
+    ensure_buf(&h->mout, &h->mout_cap, (size_t)B * out_ch * hw * sizeof(float));
+    // DiffusionWrapper 'concat' (ddpm.py:1331-1333) without materialising the cat: streams read planes in place
+    h->io.plane[0] = x;
+    h->io.plane_bs[0] = hw;
+    h->io.plane[1] = cond;
+    h->io.plane_bs[1] = (int64_t)Cc * hw;
+    if (Cc == 1) {
+        ensure_buf(&h->zplane, &h->zplane_cap, (size_t)hw * sizeof(float));
+        DSD_HIP(hipMemsetAsync(h->zplane, 0, (size_t)hw * sizeof(float), s));
+        h->io.plane[2] = h->io.plane[3] = h->zplane;
+        h->io.plane_bs[2] = h->io.plane_bs[3] = 0;
+    } else {
+        h->io.plane[2] = cond + hw;
+        h->io.plane[3] = cond + 2 * hw;
+        h->io.plane_bs[2] = h->io.plane_bs[3] = (int64_t)Cc * hw;
+    }
+    h->io.t = h->tbuf;
+    h->io.t_is_float = 1;
+    h->io.out = h->mout;
+    h->io.feats = nullptr;
+    const int k0 = first_step < 0 ? 0 : first_step;
+    const int k1 = n_steps <= 0 ? sc->steps : std::min(sc->steps, k0 + n_steps);
+    for (int k = k0; k < k1; ++k) {
+        fill_t(h->tbuf, B, sc->t_model[k], s);
+        net_run(h, s);
+        const StepCoef c = step_coef(sc, k);
+        sampler_update(c, h->mout, x, noise ? noise + (size_t)k * B * hw : nullptr, philox_seed, (uint64_t)k, B, (int)hw, s);
+    }
+    DSD_CATCH
+}
+
+int dsd_op_sampler_update(const dsd_schedule* sc, int k, const float* model_out, float* x, const float* noise,
+                          uint64_t philox_seed, int B, int H, int W, void* stream) {
+    DSD_TRY
+    check_schedule(sc);
+    DSD_CHECK(k >= 0 && k < sc->steps && model_out && x, "bad argument");
+    sampler_update(step_coef(sc, k), model_out, x, noise, philox_seed, (uint64_t)k, B, H * W, (hipStream_t)stream);
+    DSD_CATCH
+}
+
+// ------------------------------------------------------------------------------------------- kernel-level ops
+int dsd_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout, int ks,
+                  int stride, int upsample, const float* emb, const float* res, float* y, void* stream) {
+    DSD_TRY
+    hipStream_t s = (hipStream_t)stream;
+    Tmp wp((size_t)Cout * Cin * ks * ks * sizeof(float));
+    pack_ohwi(w_oihw, wp.as<float>(), Cout, Cin, ks, s);
+    ConvArgs a;
+    a.x = x; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.w = wp.as<float>(); a.bias = bias; a.Cout = Cout; a.ks = ks;
+    a.stride = stride; a.ups = upsample; a.emb = emb; a.emb_stride = Cout; a.res = res; a.y = y;
+    conv2d(a, s);
+    DSD_HIP(hipStreamSynchronize(s));
+    DSD_CATCH
+}
+
+int dsd_op_group_norm(const float* x, int N, int HW, int C, const float* gamma, const float* beta, float eps, int silu,
+                      float* y, void* stream) {
+    DSD_TRY
+    hipStream_t s = (hipStream_t)stream;
+    const int nchunk = gn_nchunks(HW, C);
+    Tmp part((size_t)N * nchunk * 32 * 2 * sizeof(double)), sc((size_t)N * C * sizeof(float)), sh((size_t)N * C * sizeof(float));
+    gn_stats(x, N, HW, C, part.as<double>(), nchunk, s);
+    gn_finalize(part.as<double>(), nchunk, N, HW, C, gamma, beta, eps, nullptr, 0, sc.as<float>(), sh.as<float>(), s);
+    affine_act(x, N, HW, C, sc.as<float>(), sh.as<float>(), silu ? ACT_SILU : ACT_NONE, y, s);
+    DSD_HIP(hipStreamSynchronize(s));
+    DSD_CATCH
+}
+
+int dsd_op_qkv_attention(const float* qkv, int N, int T, int C, int heads, int new_order, float* out, void* stream) {
+    DSD_TRY
+    DSD_CHECK(heads > 0 && C % heads == 0, "C=%d not divisible by heads=%d", C, heads);
+    const int d = C / heads;
+    AttnArgs a;
+    a.N = N; a.Tq = a.Tk = T; a.heads = heads; a.d = d;
+    a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
+    a.scale_q = a.scale_k = 1.f / std::sqrt(std::sqrt((float)d));
+    if (new_order) {
+        a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C;
+        a.q_hs = a.k_hs = a.v_hs = d;
+    } else {
+        a.q = qkv; a.k = qkv + d; a.v = qkv + 2 * d;
+        a.q_hs = a.k_hs = a.v_hs = 3 * d;
+    }
+    a.out = out;
+    attention(a, (hipStream_t)stream);
+    DSD_CATCH
+}
+
+int dsd_op_timestep_embedding(const void* t, int t_is_float, int N, int dim, float* y, void* stream) {
+    DSD_TRY
+    timestep_embedding(t, t_is_float, N, dim, y, (hipStream_t)stream);
+    DSD_CATCH
+}
+
+int dsd_op_linear(const float* x, int N, int K, const float* w, const float* bias, int O, int act_in, float* y, void* stream) {
+    DSD_TRY
+    linear(x, N, K, K, w, bias, O, act_in, y, O, (hipStream_t)stream);
+    DSD_CATCH
+}
+
+int dsd_op_philox_normal(float* y, int64_t n, uint64_t seed, uint64_t step, void* stream) {
+    DSD_TRY
+    philox_normal(y, n, seed, step, (hipStream_t)stream);
+    DSD_CATCH
+}
+
+}  // extern "C"

@@ -1,0 +1,154 @@
+// attention.hip — fp32 softmax(Q K^T) V with online softmax on the gfx950 f32 matrix cores.
+//
+// Replaces QKVAttention / QKVAttentionLegacy (ldm/modules/diffusionmodules/openaimodel.py:496-555; the two
+// einsums + fp32 softmax) and the einsum/softmax core of CrossAttention (ldm/modules/attention.py:164-193).
+//
+// One workgroup = (sample, head, 128 queries); each of the 4 waves owns 32 queries.  The score tile is
+// computed TRANSPOSED, S^T = K Q^T (A = K rows from LDS, B = Q^T held in registers), so a lane owns ONE
+// query column and 16 of the 32 keys of the tile: the softmax row reductions are in-lane plus a single
+// exchange with lane^32 (wavefront-level, no LDS).  exp(S^T) is already in the B-operand layout of the
+// second product O^T = V^T P^T, so P never leaves registers; V^T fragments are conflict-free ds_read_b32.
+// The head dim is zero-padded to a multiple of 32 (DT tiles); keys beyond Tk are masked to -inf.
+#include "kernels.h"
+
+namespace dsd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int DT>
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+    constexpr int KEYS = DT <= 2 ? 64 : 32;  // keys per LDS stage (32-key MFMA sub-tiles); keeps LDS <= 64 KB
+    constexpr int DP = DT * 32;   // padded head dim
+    constexpr int DH = DP / 2;    // per lane-half k range of the QK^T product
+    constexpr int LS = DP + 4;    // LDS row stride (floats)
+    __shared__ __attribute__((aligned(16))) float Ks[KEYS * LS];
+    __shared__ __attribute__((aligned(16))) float Vs[KEYS * LS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, half = lane >> 5;
+    const int n = blockIdx.z, head = blockIdx.y;
+    const int q = blockIdx.x * 128 + wave * 32 + lrow;
+    const bool q_ok = q < a.Tq;
+
+    // Q^T fragment (B operand): this lane's query, d in [half*DH, half*DH+DH), pre-scaled like the reference
+    float qf[DH];
+    {
+        const float* qp = a.q + ((int64_t)n * a.Tq + (q_ok ? q : 0)) * a.ldq + (int64_t)head * a.q_hs;
+#pragma unroll
+        for (int i = 0; i < DH; i += 4) {
+            const int d = half * DH + i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q_ok && d < a.d) v = *reinterpret_cast<const float4*>(qp + d);
+            qf[i] = v.x * a.scale_q;
+            qf[i + 1] = v.y * a.scale_q;
+            qf[i + 2] = v.z * a.scale_q;
+            qf[i + 3] = v.w * a.scale_q;
+        }
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const float* kbase = a.k + (int64_t)n * a.Tk * a.ldk + (int64_t)head * a.k_hs;
+    const float* vbase = a.v + (int64_t)n * a.Tk * a.ldv + (int64_t)head * a.v_hs;
+    constexpr int C4 = DP / 4;  // float4 columns per row
+    for (int k0 = 0; k0 < a.Tk; k0 += KEYS) {
+        __syncthreads();
+        for (int i = tid; i < KEYS * C4; i += 256) {
+            const int kr = i / C4, c4 = i - kr * C4;
+            const int key = k0 + kr, d = c4 * 4;
+            float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+            if (key < a.Tk && d < a.d) {
+                kv = *reinterpret_cast<const float4*>(kbase + (int64_t)key * a.ldk + d);
+                vv = *reinterpret_cast<const float4*>(vbase + (int64_t)key * a.ldv + d);
+                kv.x *= a.scale_k; kv.y *= a.scale_k; kv.z *= a.scale_k; kv.w *= a.scale_k;
+            }
+            *reinterpret_cast<float4*>(Ks + kr * LS + d) = kv;
+            *reinterpret_cast<float4*>(Vs + kr * LS + d) = vv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < KEYS / 32; ++sub) {
+            if (k0 + sub * 32 >= a.Tk) break;
+            // S^T[key][q] = sum_d K[key][d] Q[q][d]
+            f32x16 sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            const float* kf = Ks + (sub * 32 + lrow) * LS + half * DH;
+#pragma unroll
+            for (int i = 0; i < DH; i += 4) {
+                const float4 k4 = *reinterpret_cast<const float4*>(kf + i);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, qf[i], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, qf[i + 1], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, qf[i + 2], sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, qf[i + 3], sacc, 0, 0, 0);
+            }
+            // mask + online softmax; this lane holds keys (r&3)+8*(r>>2)+4*half of the sub-tile for query lrow
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                float sv = sacc[r] * a.scale_s;
+                sv = key < a.Tk ? sv : -INFINITY;
+                sacc[r] = sv;
+                tmax = fmaxf(tmax, sv);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            const float m_new = fmaxf(m_run, tmax);
+            const float corr = expf(m_run - m_new);  // m_run = -inf on the first tile -> 0
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = expf(sacc[r] - m_new);
+                sacc[r] = pv;
+                psum += pv;
+            }
+            psum += __shfl_xor(psum, 32);
+            l_run = l_run * corr + psum;
+            m_run = m_new;
+            // O^T[d][q] = corr * O^T + sum_key V[key][d] P[key][q]
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] *= corr;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const int kr = sub * 32 + (s & 3) + 8 * (s >> 2) + 4 * half;
+                    const float vf = Vs[kr * LS + t * 32 + lrow];
+                    o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, sacc[s], o[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!q_ok) return;
+    const float inv = 1.f / l_run;
+    float* op = a.out + ((int64_t)n * a.Tq + q) * a.ldo + (int64_t)head * a.d;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (d < a.d) op[d] = o[t][r] * inv;
+        }
+}
+
+void attention(const AttnArgs& a, hipStream_t s) {
+    DSD_CHECK(a.d % 4 == 0 && a.d >= 4 && a.d <= 128, "attention: head dim %d unsupported (need multiple of 4, <=128)", a.d);
+    DSD_CHECK(a.Tk >= 1 && a.Tq >= 1, "attention: empty sequence");
+    DSD_CHECK(a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.q_hs % 4 == 0 && a.k_hs % 4 == 0 && a.v_hs % 4 == 0,
+              "attention: rows must be 16-byte aligned");
+    const dim3 grid(cdiv(a.Tq, 128), a.heads, a.N), block(256);
+    const int dt = cdiv(a.d, 32);
+    switch (dt) {
+        case 1: hipLaunchKernelGGL(attention_kernel<1>, grid, block, 0, s, a); break;
+        case 2: hipLaunchKernelGGL(attention_kernel<2>, grid, block, 0, s, a); break;
+        case 3: hipLaunchKernelGGL(attention_kernel<3>, grid, block, 0, s, a); break;
+        default: hipLaunchKernelGGL(attention_kernel<4>, grid, block, 0, s, a); break;
+    }
+    check_launch("attention");
+}
+
+}  // namespace dsd

@@ -1,0 +1,364 @@
+// conv.hip — NHWC fp32 convolution as an implicit GEMM on the gfx950 f32 matrix cores.
+//
+// Replaces every nn.Conv2d / nn.Conv1d(k=1) call site on the hot path
+// (ldm/modules/diffusionmodules/util.py:229-239 conv_nd; openaimodel.py:109,155,208,234,245,452,460;
+//  UNet_DS_Diff/model.py:158,163,285,514,569-601).
+//
+//   M = N*OH*OW (output pixels), Ngemm = Cout, K = ks*ks*Cin, A gathered on the fly (im2col never
+//   materialised), B = weights packed OHWI so both operands are K-contiguous.
+//   Block = 256 threads = 4 waves; block tile 128 (M) x 32*NT (N) x 32 (K); each wave owns 32 rows and
+//   all NT 32-wide column tiles -> NT accumulators of v_mfma_f32_32x32x2_f32 (exact fp32 fma chain).
+//   LDS tiles are [row][36] floats (pad 4): the ds_read_b128 fragment reads (lane = row, 4 k's) and the
+//   ds_write_b128 staging writes are both bank-conflict free with that stride.
+//   K order inside a group of 8 is permuted (lane half h takes k = 8g+4h+j for MFMA j) identically for A
+//   and B, so one 16-byte LDS read feeds four MFMAs.
+//   Global -> register prefetch of tile kt+1 is issued before the MFMAs of tile kt (single LDS buffer,
+//   2-3 blocks per CU hide the barriers).
+//   Epilogue fuses bias, the per-(sample,channel) timestep-embedding add and the residual add.
+#include "kernels.h"
+
+namespace dsd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int BM = 128;
+static constexpr int BK = 32;
+static constexpr int LDS_STRIDE = 36;
+
+struct ConvP {
+    const float* x;
+    const float* w;
+    const float* bias;
+    const float* emb;
+    const float* res;
+    float* y;
+    int64_t x_bs;
+    int N, H, W, Cin, Cout, OH, OW, ks, stride, pad, ups, emb_stride, out_nchw;
+    int M, Ktot, cchunks, IHg, IWg, tiles_m, tiles_n, ohw;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
+    __shared__ __attribute__((aligned(16))) float lds[(BM + NT * 32) * LDS_STRIDE];
+    float* As = lds;
+    float* Bs = lds + BM * LDS_STRIDE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+
+    // XCD-aware tile order: blocks that share A rows / the weight panel run on one XCD (one L2).
+    const int nwg = gridDim.x;
+    int L = blockIdx.x;
+    {
+        const int cpx = nwg >> 3;
+        if (L < (cpx << 3)) L = (L & 7) * cpx + (L >> 3);
+    }
+    const int tile_n = L % p.tiles_n;
+    const int tile_m = L / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * (NT * 32);
+
+    // ---- staging map: thread -> (row = tid>>3 (+32 i), 4 consecutive k = 4*(tid&7))
+    const int col4 = tid & 7;
+    const int srow = tid >> 3;
+    int a_h[4], a_w[4];
+    int64_t a_nb[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + srow + 32 * i;
+        a_ok[i] = m < p.M;
+        m = a_ok[i] ? m : 0;
+        const int n = m / p.ohw;
+        const int r = m - n * p.ohw;
+        const int oh = r / p.OW;
+        const int ow = r - oh * p.OW;
+        a_h[i] = oh * p.stride - p.pad;
+        a_w[i] = ow * p.stride - p.pad;
+        a_nb[i] = (int64_t)n * p.x_bs;
+    }
+    const float* wrow[NT];
+    bool b_ok[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + srow + 32 * j;
+        b_ok[j] = n < p.Cout;
+        wrow[j] = p.w + (int64_t)(b_ok[j] ? n : 0) * p.Ktot;
+    }
+
+    float4 ra[4], rb[NT];
+    auto load_tile = [&](int kh, int kw, int cc) {
+        const int c = cc * BK + col4 * 4;
+        const bool cok = c < p.Cin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ih = a_h[i] + kh, iw = a_w[i] + kw;
+            const bool ok = a_ok[i] && cok && (unsigned)ih < (unsigned)p.IHg && (unsigned)iw < (unsigned)p.IWg;
+            if (p.ups) {
+                ih >>= 1;
+                iw >>= 1;
+            }
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) ra[i] = *reinterpret_cast<const float4*>(p.x + a_nb[i] + ((int64_t)ih * p.W + iw) * p.Cin + c);
+        }
+        const int kofs = (kh * p.ks + kw) * p.Cin + c;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_ok[j] && cok) rb[j] = *reinterpret_cast<const float4*>(wrow[j] + kofs);
+        }
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int lrow = lane & 31;
+    const int half = lane >> 5;
+    const float* a_frag = As + (wave * 32 + lrow) * LDS_STRIDE + 4 * half;
+    const float* b_frag = Bs + lrow * LDS_STRIDE + 4 * half;
+    float* a_st = As + srow * LDS_STRIDE + col4 * 4;
+    float* b_st = Bs + srow * LDS_STRIDE + col4 * 4;
+
+    const int KT = p.ks * p.ks * p.cchunks;
+    int kh = 0, kw = 0, cc = 0;
+    load_tile(kh, kw, cc);
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();  // all waves finished reading the previous tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(a_st + 32 * i * LDS_STRIDE) = ra[i];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(b_st + 32 * j * LDS_STRIDE) = rb[j];
+        __syncthreads();
+        if (kt + 1 < KT) {  // prefetch next tile into registers; lands while the MFMAs below run
+            if (++cc == p.cchunks) {
+                cc = 0;
+                if (++kw == p.ks) {
+                    kw = 0;
+                    ++kh;
+                }
+            }
+            load_tile(kh, kw, cc);
+        }
+#pragma unroll
+        for (int kg = 0; kg < 4; ++kg) {
+            const float4 a4 = *reinterpret_cast<const float4*>(a_frag + 8 * kg);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const float4 b4 = *reinterpret_cast<const float4*>(b_frag + j * 32 * LDS_STRIDE + 8 * kg);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[j], 0, 0, 0);
+                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= p.M) continue;
+        const int nb = m / p.ohw;
+        const float* embrow = p.emb ? p.emb + (int64_t)nb * p.emb_stride : nullptr;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 32 + lrow;
+            if (n >= p.Cout) continue;
+            float v = acc[j][r];
+            if (p.bias) v += p.bias[n];
+            if (embrow) v += embrow[n];
+            if (p.res) v += p.res[(int64_t)m * p.Cout + n];
+            if (p.out_nchw) {
+                const int pix = m - nb * p.ohw;
+                p.y[((int64_t)nb * p.Cout + n) * p.ohw + pix] = v;
+            } else {
+                p.y[(int64_t)m * p.Cout + n] = v;
+            }
+        }
+    }
+}
+
+// Direct kernel for tiny K (first layer: Cin = 1, K = 9): output-write bound, weights staged in LDS as [k][Cout].
+__global__ __launch_bounds__(256) void conv_direct_lds_kernel(ConvP p) {
+    extern __shared__ float wl[];  // [Ktot][Cout]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < p.Ktot * p.Cout; i += 256) {
+        const int k = i / p.Cout, co = i - k * p.Cout;
+        wl[i] = p.w[(int64_t)co * p.Ktot + k];
+    }
+    __syncthreads();
+    const int c4n = p.Cout >> 2;
+    const int PIX = 64;
+    const int64_t pix0 = (int64_t)blockIdx.x * PIX;
+    for (int idx = tid; idx < PIX * c4n; idx += 256) {
+        const int pl = idx / c4n, c4 = idx - pl * c4n;
+        const int64_t m = pix0 + pl;
+        if (m >= p.M) break;
+        const int nb = (int)(m / p.ohw);
+        const int r = (int)(m - (int64_t)nb * p.ohw);
+        const int oh = r / p.OW, ow = r - oh * p.OW;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = 0;
+        for (int kh = 0; kh < p.ks; ++kh)
+            for (int kw = 0; kw < p.ks; ++kw) {
+                int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+                const bool ok = (unsigned)ih < (unsigned)p.IHg && (unsigned)iw < (unsigned)p.IWg;
+                if (p.ups) {
+                    ih >>= 1;
+                    iw >>= 1;
+                }
+                const float* src = p.x + (int64_t)nb * p.x_bs + ((int64_t)ih * p.W + iw) * p.Cin;
+                for (int ci = 0; ci < p.Cin; ++ci, ++k) {
+                    const float xv = ok ? src[ci] : 0.f;
+                    const float4 w4 = *reinterpret_cast<const float4*>(wl + k * p.Cout + c4 * 4);
+                    acc.x = fmaf(xv, w4.x, acc.x);
+                    acc.y = fmaf(xv, w4.y, acc.y);
+                    acc.z = fmaf(xv, w4.z, acc.z);
+                    acc.w = fmaf(xv, w4.w, acc.w);
+                }
+            }
+        float v[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = c4 * 4 + q;
+            if (p.bias) v[q] += p.bias[n];
+            if (p.emb) v[q] += p.emb[(int64_t)nb * p.emb_stride + n];
+            if (p.res) v[q] += p.res[m * p.Cout + n];
+        }
+        if (p.out_nchw) {
+            for (int q = 0; q < 4; ++q) p.y[((int64_t)nb * p.Cout + c4 * 4 + q) * p.ohw + r] = v[q];
+        } else {
+            *reinterpret_cast<float4*>(p.y + m * p.Cout + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+// Fully generic scalar fallback (odd channel counts; never on the hot configs).
+__global__ __launch_bounds__(256) void conv_scalar_kernel(ConvP p) {
+    const int64_t total = (int64_t)p.M * p.Cout;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t m = i / p.Cout;
+        const int n = (int)(i - m * p.Cout);
+        const int nb = (int)(m / p.ohw);
+        const int r = (int)(m - (int64_t)nb * p.ohw);
+        const int oh = r / p.OW, ow = r - oh * p.OW;
+        float acc = 0.f;
+        const float* wr = p.w + (int64_t)n * p.Ktot;
+        for (int kh = 0; kh < p.ks; ++kh)
+            for (int kw = 0; kw < p.ks; ++kw) {
+                int ih = oh * p.stride - p.pad + kh, iw = ow * p.stride - p.pad + kw;
+                if (!((unsigned)ih < (unsigned)p.IHg && (unsigned)iw < (unsigned)p.IWg)) continue;
+                if (p.ups) {
+                    ih >>= 1;
+                    iw >>= 1;
+                }
+                const float* src = p.x + (int64_t)nb * p.x_bs + ((int64_t)ih * p.W + iw) * p.Cin;
+                const float* wk = wr + (kh * p.ks + kw) * p.Cin;
+                for (int ci = 0; ci < p.Cin; ++ci) acc = fmaf(src[ci], wk[ci], acc);
+            }
+        if (p.bias) acc += p.bias[n];
+        if (p.emb) acc += p.emb[(int64_t)nb * p.emb_stride + n];
+        if (p.res) acc += p.res[m * p.Cout + n];
+        if (p.out_nchw)
+            p.y[((int64_t)nb * p.Cout + n) * p.ohw + r] = acc;
+        else
+            p.y[m * p.Cout + n] = acc;
+    }
+}
+
+__global__ void pack_ohwi_kernel(const float* __restrict__ src, float* __restrict__ dst, int Cout, int Cin, int kk) {
+    const int64_t total = (int64_t)Cout * Cin * kk;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        // dst index: ((co*kk + t)*Cin + ci)
+        const int ci = (int)(i % Cin);
+        const int64_t r = i / Cin;
+        const int t = (int)(r % kk);
+        const int co = (int)(r / kk);
+        dst[i] = src[((int64_t)co * Cin + ci) * kk + t];
+    }
+}
+
+void pack_ohwi(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, hipStream_t s) {
+    const int64_t total = (int64_t)Cout * Cin * ks * ks;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 65535);
+    hipLaunchKernelGGL(pack_ohwi_kernel, dim3(blocks), dim3(256), 0, s, w_oihw, w_ohwi, Cout, Cin, ks * ks);
+    check_launch("pack_ohwi");
+}
+
+double conv2d_flops(const ConvArgs& a) {
+    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W;
+    const int pad = a.ks / 2;
+    const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
+    return 2.0 * a.N * OH * OW * (double)a.Cout * a.ks * a.ks * a.Cin;
+}
+
+static int pick_nt(int Cout, int tiles_m) {
+    const int t32 = cdiv(Cout, 32);
+    int best = 1, best_waste = 1 << 30;
+    for (int nt = 5; nt >= 1; --nt) {
+        const int waste = cdiv(t32, nt) * nt - t32;
+        if (waste < best_waste) {
+            best_waste = waste;
+            best = nt;
+        }
+    }
+    // keep >= ~2 blocks per CU on small-M layers by narrowing the N tile
+    while (best > 1 && (int64_t)tiles_m * cdiv(t32, best) < 512) {
+        int nb = best - 1;
+        while (nb > 1 && (cdiv(t32, nb) * nb - t32) > best_waste) --nb;
+        best = nb;
+    }
+    return best;
+}
+
+void conv2d(ConvArgs a, hipStream_t s) {
+    DSD_CHECK(a.ks == 1 || a.ks == 3, "conv2d: kernel size %d unsupported", a.ks);
+    DSD_CHECK(a.stride == 1 || a.stride == 2, "conv2d: stride %d unsupported", a.stride);
+    ConvP p{};
+    p.x = a.x; p.w = a.w; p.bias = a.bias; p.emb = a.emb; p.res = a.res; p.y = a.y;
+    p.N = a.N; p.H = a.H; p.W = a.W; p.Cin = a.Cin; p.Cout = a.Cout; p.ks = a.ks; p.stride = a.stride;
+    p.pad = a.ks / 2; p.ups = a.ups; p.emb_stride = a.emb_stride; p.out_nchw = a.out_nchw;
+    p.x_bs = a.x_bs >= 0 ? a.x_bs : (int64_t)a.H * a.W * a.Cin;
+    p.IHg = a.ups ? a.H * 2 : a.H;
+    p.IWg = a.ups ? a.W * 2 : a.W;
+    p.OH = (p.IHg + 2 * p.pad - a.ks) / a.stride + 1;
+    p.OW = (p.IWg + 2 * p.pad - a.ks) / a.stride + 1;
+    p.ohw = p.OH * p.OW;
+    const int64_t M64 = (int64_t)a.N * p.ohw;
+    DSD_CHECK(M64 < (1ll << 31) && M64 * std::max(a.Cout, a.Cin) < (1ll << 40), "conv2d: problem too large");
+    p.M = (int)M64;
+    p.Ktot = a.ks * a.ks * a.Cin;
+    p.cchunks = cdiv(a.Cin, BK);
+    p.tiles_m = cdiv(p.M, BM);
+    if (p.M == 0 || a.Cout == 0) return;
+
+    if (a.Cin % 4 != 0 || p.Ktot < 32) {
+        const size_t lds = (size_t)p.Ktot * a.Cout * sizeof(float);
+        if (a.Cout % 4 == 0 && lds <= 60 * 1024) {
+            hipLaunchKernelGGL(conv_direct_lds_kernel, dim3(cdiv(p.M, 64)), dim3(256), lds, s, p);
+            check_launch("conv_direct_lds");
+        } else {
+            const int blocks = (int)std::min<int64_t>(((int64_t)p.M * a.Cout + 255) / 256, 1 << 20);
+            hipLaunchKernelGGL(conv_scalar_kernel, dim3(blocks), dim3(256), 0, s, p);
+            check_launch("conv_scalar");
+        }
+        return;
+    }
+    const int nt = pick_nt(a.Cout, p.tiles_m);
+    p.tiles_n = cdiv(a.Cout, nt * 32);
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    switch (nt) {
+        case 1: hipLaunchKernelGGL(conv_mfma_kernel<1>, grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL(conv_mfma_kernel<2>, grid, dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL(conv_mfma_kernel<3>, grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL(conv_mfma_kernel<4>, grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL(conv_mfma_kernel<5>, grid, dim3(256), 0, s, p); break;
+    }
+    check_launch("conv_mfma");
+}
+
+}  // namespace dsd

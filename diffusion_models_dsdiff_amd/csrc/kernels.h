@@ -1,0 +1,80 @@
+// Launcher declarations for the hand-written gfx950 kernels of libdsdiff.
+#pragma once
+#include "common.h"
+
+namespace dsd {
+
+// ---------------------------------------------------------------- conv.hip
+// Implicit-GEMM convolution on NHWC fp32, f32 MFMA (v_mfma_f32_32x32x2_f32), M = N*OH*OW, N = Cout, K = ks*ks*Cin.
+struct ConvArgs {
+    const float* x = nullptr;   // input, NHWC within a sample
+    int N = 0, H = 0, W = 0, Cin = 0;
+    int64_t x_bs = -1;          // batch stride of x in elements (<0 -> H*W*Cin; 0 = one plane shared by all samples)
+    const float* w = nullptr;   // packed OHWI: [Cout][ks*ks*Cin]
+    const float* bias = nullptr;
+    int Cout = 0, ks = 3, stride = 1;
+    int ups = 0;                // nearest x2 folded into the gather (Upsample, openaimodel.py:111-121)
+    const float* emb = nullptr; // per-(n,co) add: emb[n*emb_stride + co]   (ResBlock h + emb_out, openaimodel.py:282)
+    int emb_stride = 0;
+    const float* res = nullptr; // residual NHWC [N,OH,OW,Cout] added in the epilogue (skip_connection(x) + h)
+    float* y = nullptr;
+    int out_nchw = 0;           // store as [N,Cout,OH,OW] (final layer with out_channels > 1)
+    int OH = 0, OW = 0;         // filled by conv2d()
+};
+void conv2d(ConvArgs a, hipStream_t s);
+double conv2d_flops(const ConvArgs& a);
+void pack_ohwi(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, hipStream_t s);
+
+// ---------------------------------------------------------------- norm.hip
+int gn_nchunks(int HW, int C);
+// partial: [N][nchunk][32][2] doubles (sum, sumsq)
+void gn_stats(const float* x, int N, int HW, int C, double* partial, int nchunk, hipStream_t s);
+// scale/shift: [N][C] so that GN(x) = x*scale + shift; film (optional, [N][film_stride] = scale|shift halves):
+// (GN(x))*(1+fs)+fsh folded in (ResBlock use_scale_shift_norm, openaimodel.py:276-280)
+void gn_finalize(const double* partial, int nchunk, int N, int HW, int C, const float* gamma, const float* beta,
+                 float eps, const float* film, int film_stride, float* scale, float* shift, hipStream_t s);
+enum { ACT_NONE = 0, ACT_SILU = 1 };
+void affine_act(const float* x, int N, int HW, int C, const float* scale, const float* shift, int act, float* y,
+                hipStream_t s);
+void layer_norm(const float* x, int64_t rows, int C, const float* gamma, const float* beta, float eps, float* y,
+                hipStream_t s);
+
+// ---------------------------------------------------------------- attention.hip
+struct AttnArgs {
+    const float *q = nullptr, *k = nullptr, *v = nullptr;  // rows of ld* floats, head h at +h*hs*
+    int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
+    int q_hs = 0, k_hs = 0, v_hs = 0;
+    int N = 0, Tq = 0, Tk = 0, heads = 0, d = 0;
+    float scale_q = 1.f, scale_k = 1.f, scale_s = 1.f;
+    float* out = nullptr;  // [N][Tq][ldo], head h at +h*d
+};
+void attention(const AttnArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- misc.hip
+void timestep_embedding(const void* t, int t_is_float, int N, int dim, float* y, hipStream_t s);
+void linear(const float* x, int N, int K, int ldx, const float* w, const float* bias, int O, int act_in, float* y,
+            int ldy, hipStream_t s);
+void se_scale(const float* x, int N, int HW, int C, const float* w1, const float* w2, int Cr, float* y, hipStream_t s);
+// dst[p, coff:coff+C] = act((a+b+c+d) * scale), sources NHWC [pixels][C]
+void avg_into(const float* a, const float* b, const float* c, const float* d, float scale, int64_t pixels, int C,
+              float* dst, int dstC, int coff, int act, hipStream_t s);
+void nchw_to_nhwc(const float* x, int N, int C, int HW, float* y, hipStream_t s);
+void nhwc_to_nchw(const float* x, int N, int C, int HW, float* y, hipStream_t s);
+void avgpool2(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);
+void upsample2(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);
+void geglu(const float* x, int64_t rows, int inner, float* y, hipStream_t s);
+void add2(const float* a, const float* b, int64_t n, float* y, hipStream_t s);
+
+// ---------------------------------------------------------------- sampler.hip
+struct StepCoef {
+    float c[8];
+    int mode, pred, learned_range, clip, nonzero;
+    float eta;
+};
+// model_out: [B,Cm,HW] (Cm = 1, or 2 with learned_range); x in/out [B,1,HW]; noise [B,1,HW] or null (Philox)
+void sampler_update(const StepCoef& sc, const float* model_out, float* x, const float* noise, uint64_t seed,
+                    uint64_t step, int B, int HW, hipStream_t s);
+void philox_normal(float* y, int64_t n, uint64_t seed, uint64_t step, hipStream_t s);
+void fill_t(float* t, int B, float v, hipStream_t s);
+
+}  // namespace dsd

@@ -1,0 +1,271 @@
+// misc.hip — the small kernels around the convolutions: timestep embedding, tiny linears, SE gate,
+// skip-average / concat, layout changes, resampling, GEGLU.
+#include "kernels.h"
+
+namespace dsd {
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + expf(-v)); }
+
+// timestep_embedding, ldm/modules/diffusionmodules/util.py:161-181: cat[cos(t*f), sin(t*f)], f_k = exp(-ln(1e4)*k/half)
+// evaluated like the reference in fp32 (the fp32 argument is formed with fp32 ops, exp itself is taken in fp64 and rounded once).
+__global__ void timestep_embedding_kernel(const void* __restrict__ t, int t_is_float, int N, int dim, float* __restrict__ y) {
+    const int half = dim / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * half) return;
+    const int n = i / half, k = i - n * half;
+    const float tv = t_is_float ? ((const float*)t)[n] : (float)((const long long*)t)[n];
+    const float neg_log = -9.210340371976184f;  // (float)(-math.log(10000))
+    const float arg = (neg_log * (float)k) / (float)half;
+    const float f = (float)exp((double)arg);
+    const float a = tv * f;
+    y[(int64_t)n * dim + k] = cosf(a);
+    y[(int64_t)n * dim + half + k] = sinf(a);
+    if ((dim & 1) && k == 0) y[(int64_t)n * dim + dim - 1] = 0.f;
+}
+
+void timestep_embedding(const void* t, int t_is_float, int N, int dim, float* y, hipStream_t s) {
+    const int total = N * (dim / 2);
+    if (total == 0) return;
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t, t_is_float, N, dim, y);
+    check_launch("timestep_embedding");
+}
+
+// y[n][o] = bias[o] + sum_k act(x[n][k]) * w[o][k].  One wave per output row o, 8 batch rows at a time.
+template <int ACT>
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ x, int N, int K, int ldx,
+                                                     const float* __restrict__ w, const float* __restrict__ bias, int O,
+                                                     float* __restrict__ y, int ldy) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= O) return;
+    const float* wr = w + (int64_t)o * K;
+    const bool vec = (K % 4 == 0) && (ldx % 4 == 0);
+    for (int n0 = 0; n0 < N; n0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+        if (vec) {
+            for (int k = lane * 4; k < K; k += 256) {
+                const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (n0 + j < N) {
+                        float4 v = *reinterpret_cast<const float4*>(x + (int64_t)(n0 + j) * ldx + k);
+                        if (ACT == ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+                        acc[j] = fmaf(v.x, w4.x, acc[j]);
+                        acc[j] = fmaf(v.y, w4.y, acc[j]);
+                        acc[j] = fmaf(v.z, w4.z, acc[j]);
+                        acc[j] = fmaf(v.w, w4.w, acc[j]);
+                    }
+                }
+            }
+        } else {
+            for (int k = lane; k < K; k += 64) {
+                const float wv = wr[k];
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (n0 + j < N) {
+                        float v = x[(int64_t)(n0 + j) * ldx + k];
+                        if (ACT == ACT_SILU) v = silu_f(v);
+                        acc[j] = fmaf(v, wv, acc[j]);
+                    }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = acc[j];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && n0 + j < N) y[(int64_t)(n0 + j) * ldy + o] = v + (bias ? bias[o] : 0.f);
+        }
+    }
+}
+
+void linear(const float* x, int N, int K, int ldx, const float* w, const float* bias, int O, int act_in, float* y,
+            int ldy, hipStream_t s) {
+    if (N == 0 || O == 0) return;
+    const dim3 grid(cdiv(O, 4)), block(256);
+    if (act_in == ACT_SILU)
+        hipLaunchKernelGGL(linear_kernel<ACT_SILU>, grid, block, 0, s, x, N, K, ldx, w, bias, O, y, ldy);
+    else
+        hipLaunchKernelGGL(linear_kernel<ACT_NONE>, grid, block, 0, s, x, N, K, ldx, w, bias, O, y, ldy);
+    check_launch("linear");
+}
+
+// SE_Attention (Disc_diff/guided_diffusion/unet.py:82-109): y = x * sigmoid(W2 relu(W1 avgpool(x))). One block per sample.
+__global__ __launch_bounds__(256) void se_scale_kernel(const float* __restrict__ x, int HW, int C,
+                                                       const float* __restrict__ w1, const float* __restrict__ w2, int Cr,
+                                                       float* __restrict__ y) {
+    extern __shared__ float sm[];  // pooled[C], hid[Cr], gate[C]
+    float* pooled = sm;
+    float* hid = sm + C;
+    float* gate = hid + Cr;
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float* xb = x + (int64_t)n * HW * C;
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += xb[(int64_t)p * C + c];
+        pooled[c] = s / (float)HW;
+    }
+    __syncthreads();
+    for (int j = tid; j < Cr; j += 256) {
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s = fmaf(w1[(int64_t)j * C + c], pooled[c], s);
+        hid[j] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f;
+        for (int j = 0; j < Cr; ++j) s = fmaf(w2[(int64_t)c * Cr + j], hid[j], s);
+        gate[c] = 1.f / (1.f + expf(-s));
+    }
+    __syncthreads();
+    float* yb = y + (int64_t)n * HW * C;
+    for (int64_t i = tid; i < (int64_t)HW * C; i += 256) yb[i] = xb[i] * gate[i % C];
+}
+
+void se_scale(const float* x, int N, int HW, int C, const float* w1, const float* w2, int Cr, float* y, hipStream_t s) {
+    if (N == 0) return;
+    const size_t lds = (size_t)(2 * C + Cr) * sizeof(float);
+    hipLaunchKernelGGL(se_scale_kernel, dim3(N), dim3(256), lds, s, x, HW, C, w1, w2, Cr, y);
+    check_launch("se_scale");
+}
+
+// dst[p, coff:coff+C] = act((a [+b] [+c] [+d]) / div)   — skip average (model.py:745), mean(stack) (:722-725), concat slices
+template <int ACT>
+__global__ __launch_bounds__(256) void avg_into_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                       const float4* __restrict__ c, const float4* __restrict__ d,
+                                                       float div, int64_t total4, int cols, float* __restrict__ dst,
+                                                       int dstC, int coff) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        float4 v = a[i];
+        if (b) { const float4 t = b[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (c) { const float4 t = c[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (d) { const float4 t = d[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (div != 1.f) { v.x /= div; v.y /= div; v.z /= div; v.w /= div; }
+        if (ACT == ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+        const int64_t p = i / cols;
+        const int c4 = (int)(i - p * cols);
+        *reinterpret_cast<float4*>(dst + p * dstC + coff + c4 * 4) = v;
+    }
+}
+
+void avg_into(const float* a, const float* b, const float* c, const float* d, float div, int64_t pixels, int C, float* dst,
+              int dstC, int coff, int act, hipStream_t s) {
+    DSD_CHECK(C % 4 == 0 && dstC % 4 == 0 && coff % 4 == 0, "avg_into: channel counts must be multiples of 4");
+    const int cols = C / 4;
+    const int64_t total = pixels * cols;
+    if (total == 0) return;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
+    if (act == ACT_SILU)
+        hipLaunchKernelGGL(avg_into_kernel<ACT_SILU>, dim3(blocks), dim3(256), 0, s, (const float4*)a, (const float4*)b,
+                           (const float4*)c, (const float4*)d, div, total, cols, dst, dstC, coff);
+    else
+        hipLaunchKernelGGL(avg_into_kernel<ACT_NONE>, dim3(blocks), dim3(256), 0, s, (const float4*)a, (const float4*)b,
+                           (const float4*)c, (const float4*)d, div, total, cols, dst, dstC, coff);
+    check_launch("avg_into");
+}
+
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ x, int C, int HW, int64_t total, float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int64_t r = i / C;
+        const int p = (int)(r % HW);
+        const int64_t n = r / HW;
+        y[i] = x[(n * C + c) * HW + p];
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ x, int C, int HW, int64_t total, float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int p = (int)(i % HW);
+        const int64_t r = i / HW;
+        const int c = (int)(r % C);
+        const int64_t n = r / C;
+        y[i] = x[(n * HW + p) * C + c];
+    }
+}
+void nchw_to_nhwc(const float* x, int N, int C, int HW, float* y, hipStream_t s) {
+    const int64_t total = (int64_t)N * C * HW;
+    if (!total) return;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65535)), dim3(256), 0, s, x, C, HW, total, y);
+    check_launch("nchw_to_nhwc");
+}
+void nhwc_to_nchw(const float* x, int N, int C, int HW, float* y, hipStream_t s) {
+    const int64_t total = (int64_t)N * C * HW;
+    if (!total) return;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65535)), dim3(256), 0, s, x, C, HW, total, y);
+    check_launch("nhwc_to_nchw");
+}
+
+// AvgPool2d(2,2) (Downsample without conv, openaimodel.py:160) / nearest x2 (Upsample without conv, :118), NHWC
+__global__ void avgpool2_kernel(const float4* __restrict__ x, int H, int W, int cols, int64_t total4, float4* __restrict__ y) {
+    const int OH = H / 2, OW = W / 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % cols);
+        int64_t r = i / cols;
+        const int ow = (int)(r % OW); r /= OW;
+        const int oh = (int)(r % OH);
+        const int64_t n = r / OH;
+        const float4* b = x + ((n * H + 2 * oh) * W + 2 * ow) * cols + c4;
+        const float4 v0 = b[0], v1 = b[cols], v2 = b[(int64_t)W * cols], v3 = b[(int64_t)W * cols + cols];
+        float4 o;
+        o.x = (v0.x + v1.x + v2.x + v3.x) * 0.25f;
+        o.y = (v0.y + v1.y + v2.y + v3.y) * 0.25f;
+        o.z = (v0.z + v1.z + v2.z + v3.z) * 0.25f;
+        o.w = (v0.w + v1.w + v2.w + v3.w) * 0.25f;
+        y[i] = o;
+    }
+}
+__global__ void upsample2_kernel(const float4* __restrict__ x, int H, int W, int cols, int64_t total4, float4* __restrict__ y) {
+    const int OH = H * 2, OW = W * 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % cols);
+        int64_t r = i / cols;
+        const int ow = (int)(r % OW); r /= OW;
+        const int oh = (int)(r % OH);
+        const int64_t n = r / OH;
+        y[i] = x[((n * H + (oh >> 1)) * W + (ow >> 1)) * cols + c4];
+    }
+}
+void avgpool2(const float* x, int N, int H, int W, int C, float* y, hipStream_t s) {
+    DSD_CHECK(C % 4 == 0 && H % 2 == 0 && W % 2 == 0, "avgpool2: bad shape");
+    const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
+    if (!total) return;
+    hipLaunchKernelGGL(avgpool2_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65535)), dim3(256), 0, s, (const float4*)x, H, W, C / 4, total, (float4*)y);
+    check_launch("avgpool2");
+}
+void upsample2(const float* x, int N, int H, int W, int C, float* y, hipStream_t s) {
+    DSD_CHECK(C % 4 == 0, "upsample2: bad shape");
+    const int64_t total = (int64_t)N * H * 2 * W * 2 * (C / 4);
+    if (!total) return;
+    hipLaunchKernelGGL(upsample2_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65535)), dim3(256), 0, s, (const float4*)x, H, W, C / 4, total, (float4*)y);
+    check_launch("upsample2");
+}
+
+// GEGLU (ldm/modules/attention.py:47-55): y = a * gelu(gate), [a | gate] = x row halves; exact erf GELU.
+__global__ void geglu_kernel(const float* __restrict__ x, int64_t rows, int inner, float* __restrict__ y) {
+    const int64_t total = rows * inner;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / inner;
+        const int c = (int)(i - r * inner);
+        const float a = x[r * 2 * inner + c];
+        const float g = x[r * 2 * inner + inner + c];
+        y[i] = a * (0.5f * g * (1.f + erff(g * 0.70710678118654752440f)));
+    }
+}
+void geglu(const float* x, int64_t rows, int inner, float* y, hipStream_t s) {
+    const int64_t total = rows * inner;
+    if (!total) return;
+    hipLaunchKernelGGL(geglu_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65535)), dim3(256), 0, s, x, rows, inner, y);
+    check_launch("geglu");
+}
+
+__global__ void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = a[i] + b[i];
+}
+void add2(const float* a, const float* b, int64_t n, float* y, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(add2_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)), dim3(256), 0, s, a, b, n, y);
+    check_launch("add2");
+}
+
+}  // namespace dsd

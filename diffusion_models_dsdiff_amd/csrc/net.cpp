@@ -1,0 +1,1028 @@
+// net.cpp — builds the launch plan of the DSUnetModel forward (and of single blocks) over the hand-written
+// kernels, owns the parameter slab and the liveness-planned workspace arena.
+//
+// Graph structure follows UNet_DS_Diff/model.py:282-515 (ctor) and :629-756 (forward); blocks follow
+// ldm/modules/diffusionmodules/openaimodel.py (ResBlock :264-284, AttentionBlock :467-473, Upsample :111-121,
+// Downsample :162-164), UNet_DS_Diff/model.py:152-168 (FeatureDisentangle), Disc_diff/guided_diffusion/unet.py:82-109
+// (SE_Attention) and ldm/modules/attention.py (CrossAttention :164-193, BasicTransformerBlock :326-330,
+// SpatialTransformer :411-428).
+#include "net.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+using namespace dsd;
+
+// =============================================================================================== arena
+size_t ArenaPlanner::alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    int best = -1;
+    for (int i = 0; i < (int)free_list.size(); ++i)
+        if (free_list[i].size >= bytes && (best < 0 || free_list[i].size < free_list[best].size)) best = i;
+    if (best >= 0) {
+        const size_t off = free_list[best].off;
+        free_list[best].off += bytes;
+        free_list[best].size -= bytes;
+        if (free_list[best].size == 0) free_list.erase(free_list.begin() + best);
+        return off;
+    }
+    // extend the top (absorbing a free block that touches it)
+    if (!free_list.empty() && free_list.back().off + free_list.back().size == top) {
+        const size_t off = free_list.back().off;
+        free_list.pop_back();
+        top = off + bytes;
+        peak = std::max(peak, top);
+        return off;
+    }
+    const size_t off = top;
+    top += bytes;
+    peak = std::max(peak, top);
+    return off;
+}
+
+void ArenaPlanner::release(size_t off, size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    auto it = std::lower_bound(free_list.begin(), free_list.end(), off, [](const Blk& b, size_t o) { return b.off < o; });
+    it = free_list.insert(it, Blk{off, bytes});
+    // coalesce with next / previous
+    if (it + 1 != free_list.end() && it->off + it->size == (it + 1)->off) {
+        it->size += (it + 1)->size;
+        free_list.erase(it + 1);
+    }
+    if (it != free_list.begin() && (it - 1)->off + (it - 1)->size == it->off) {
+        (it - 1)->size += it->size;
+        free_list.erase(it);
+    }
+}
+
+// =============================================================================================== spec
+namespace {
+
+enum { L_CONV, L_RES, L_ATTN, L_DOWN, L_UP };
+struct Layer {
+    int kind = 0, cin = 0, cout = 0, ch = 0, heads = 0;
+    bool up = false, down = false;
+};
+struct Spec {
+    std::vector<std::vector<Layer>> input_blocks, output_blocks;
+    std::vector<Layer> middle;
+    int conv_ch = 0, half = 0, final_ch = 0, ted = 0;
+};
+
+Layer mk_res(int cin, int cout, bool up = false, bool down = false) {
+    Layer l;
+    l.kind = L_RES; l.cin = cin; l.cout = cout; l.up = up; l.down = down;
+    return l;
+}
+
+// model.py:282-515
+Spec build_spec(const dsd_config& c) {
+    Spec s;
+    const int mc = c.model_channels;
+    DSD_CHECK(c.n_levels >= 1 && c.n_levels <= DSD_MAX_LEVELS, "channel_mult must have 1..%d entries", DSD_MAX_LEVELS);
+    DSD_CHECK(c.in_channels == 1, "in_channels must be 1: every stream of DSUnetModel.forward receives one plane (model.py:654-663)");
+    int num_heads = c.num_heads, num_heads_upsample = c.num_heads_upsample;
+    if (num_heads_upsample == -1) num_heads_upsample = num_heads;
+    const int nhc = c.num_head_channels;
+    DSD_CHECK(!(num_heads == -1 && nhc == -1), "Either num_heads or num_head_channels has to be set");
+    auto in_attn = [&](int ds) {
+        for (int i = 0; i < c.n_attention_resolutions; ++i)
+            if (c.attention_resolutions[i] == ds) return true;
+        return false;
+    };
+    auto attn = [&](int ch, int heads_arg) {
+        int dim_head;
+        if (nhc == -1) {
+            dim_head = ch / num_heads;
+        } else {
+            num_heads = ch / nhc;
+            dim_head = nhc;
+        }
+        if (c.legacy) dim_head = nhc;
+        const int h_arg = heads_arg < 0 ? num_heads : heads_arg;
+        Layer l;
+        l.kind = L_ATTN; l.ch = ch;
+        if (dim_head == -1) {
+            l.heads = h_arg;
+        } else {
+            DSD_CHECK(ch % dim_head == 0, "q,k,v channels %d is not divisible by num_head_channels %d", ch, dim_head);
+            l.heads = ch / dim_head;
+        }
+        return l;
+    };
+    Layer first;
+    first.kind = L_CONV; first.cin = c.in_channels; first.cout = mc;
+    s.input_blocks.push_back({first});
+    std::vector<int> chans{mc};
+    int ch = mc, ds = 1;
+    for (int level = 0; level < c.n_levels; ++level) {
+        const int mult = c.channel_mult[level];
+        for (int nr = 0; nr < c.num_res_blocks[level]; ++nr) {
+            std::vector<Layer> layers{mk_res(ch, mult * mc)};
+            ch = mult * mc;
+            if (in_attn(ds)) layers.push_back(attn(ch, -1));
+            s.input_blocks.push_back(layers);
+            chans.push_back(ch);
+        }
+        if (level != c.n_levels - 1) {
+            if (c.resblock_updown) {
+                s.input_blocks.push_back({mk_res(ch, ch, false, true)});
+            } else {
+                Layer d;
+                d.kind = L_DOWN; d.ch = ch;
+                s.input_blocks.push_back({d});
+            }
+            chans.push_back(ch);
+            ds *= 2;
+        }
+    }
+    s.middle = {mk_res(ch, ch), attn(ch, -1), mk_res(ch, ch)};
+    for (int level = c.n_levels - 1; level >= 0; --level) {
+        const int mult = c.channel_mult[level];
+        for (int i = 0; i < c.num_res_blocks[level] + 1; ++i) {
+            const int ich = chans.back();
+            chans.pop_back();
+            std::vector<Layer> layers{mk_res(ch + ich, mc * mult)};
+            ch = mc * mult;
+            if (in_attn(ds)) layers.push_back(attn(ch, num_heads_upsample));
+            if (level && i == c.num_res_blocks[level]) {
+                if (c.resblock_updown) {
+                    layers.push_back(mk_res(ch, ch, true, false));
+                } else {
+                    Layer u;
+                    u.kind = L_UP; u.ch = ch;
+                    layers.push_back(u);
+                }
+                ds /= 2;
+            }
+            s.output_blocks.push_back(layers);
+        }
+    }
+    s.conv_ch = c.channel_mult[0] * mc * c.channel_mult[c.n_levels - 1];
+    s.half = s.conv_ch / 2;
+    s.final_ch = ch;
+    s.ted = mc * 4;
+    DSD_CHECK(s.final_ch == mc, "out.0 normalises %d channels but out.2 expects model_channels=%d", s.final_ch, mc);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------- params
+void add_param(dsd_handle* h, const std::string& name, std::vector<int64_t> shape, bool pack3x3 = false, int region = 0) {
+    DSD_CHECK(!h->pidx.count(name), "duplicate parameter %s", name.c_str());
+    Param p;
+    p.name = name; p.shape = shape; p.pack3x3 = pack3x3; p.region = region;
+    p.numel = 1;
+    for (auto d : shape) p.numel *= d;
+    h->pidx[name] = (int)h->params.size();
+    h->params.push_back(p);
+}
+void p_lin(dsd_handle* h, const std::string& n, int cin, int cout, bool bias = true, int wregion = 0) {
+    add_param(h, n + ".weight", {cout, cin}, false, wregion);
+    if (bias) add_param(h, n + ".bias", {cout}, false, wregion ? wregion + 1 : 0);
+}
+void p_conv(dsd_handle* h, const std::string& n, int cin, int cout, int k) {
+    add_param(h, n + ".weight", {cout, cin, k, k}, k == 3);
+    add_param(h, n + ".bias", {cout});
+}
+void p_conv1d(dsd_handle* h, const std::string& n, int cin, int cout) {
+    add_param(h, n + ".weight", {cout, cin, 1});
+    add_param(h, n + ".bias", {cout});
+}
+void p_norm(dsd_handle* h, const std::string& n, int c) {
+    add_param(h, n + ".weight", {c});
+    add_param(h, n + ".bias", {c});
+}
+void p_res(dsd_handle* h, const std::string& p, int cin, int cout, int ted, bool film, bool emb_region) {
+    p_norm(h, p + ".in_layers.0", cin);
+    p_conv(h, p + ".in_layers.2", cin, cout, 3);
+    p_lin(h, p + ".emb_layers.1", ted, film ? 2 * cout : cout, true, emb_region ? 1 : 0);
+    p_norm(h, p + ".out_layers.0", cout);
+    p_conv(h, p + ".out_layers.3", cout, cout, 3);
+    if (cin != cout) p_conv(h, p + ".skip_connection", cin, cout, 1);
+}
+void p_attn(dsd_handle* h, const std::string& p, int ch) {
+    p_norm(h, p + ".norm", ch);
+    p_conv1d(h, p + ".qkv", ch, 3 * ch);
+    p_conv1d(h, p + ".proj_out", ch, ch);
+}
+void p_layer(dsd_handle* h, const std::string& p, const Layer& L, int ted, bool film) {
+    switch (L.kind) {
+        case L_CONV: p_conv(h, p, L.cin, L.cout, 3); break;
+        case L_RES: p_res(h, p, L.cin, L.cout, ted, film, true); break;
+        case L_ATTN: p_attn(h, p, L.ch); break;
+        case L_DOWN: p_conv(h, p + ".op", L.ch, L.ch, 3); break;
+        case L_UP: p_conv(h, p + ".conv", L.ch, L.ch, 3); break;
+    }
+}
+void p_disentangle(dsd_handle* h, const std::string& n, int cc, int half) {
+    p_norm(h, n + ".conv_1.0", cc);
+    p_conv(h, n + ".conv_1.2", cc, cc, 3);
+    p_norm(h, n + ".conv_2.0", cc);
+    p_conv(h, n + ".conv_2.2", cc, half, 1);
+}
+void p_xattn(dsd_handle* h, const std::string& p, int qd, int cd, int heads, int dh) {
+    const int inner = heads * dh;
+    p_lin(h, p + ".to_q", qd, inner, false);
+    p_lin(h, p + ".to_k", cd, inner, false);
+    p_lin(h, p + ".to_v", cd, inner, false);
+    p_lin(h, p + ".to_out.0", inner, qd);
+}
+void p_ff(dsd_handle* h, const std::string& p, int dim, int mult) {
+    p_lin(h, p + ".net.0.proj", dim, dim * mult * 2);
+    p_lin(h, p + ".net.2", dim * mult, dim);
+}
+void p_btb(dsd_handle* h, const std::string& p, int dim, int heads, int dh, int cd) {
+    p_xattn(h, p + ".attn1", dim, dim, heads, dh);
+    p_ff(h, p + ".ff", dim, 4);
+    p_xattn(h, p + ".attn2", dim, cd, heads, dh);
+    p_norm(h, p + ".norm1", dim);
+    p_norm(h, p + ".norm2", dim);
+    p_norm(h, p + ".norm3", dim);
+}
+
+std::string pre(const std::string& p, const std::string& n) { return p.empty() ? n : p + "." + n; }
+
+}  // namespace
+
+float* dsd_handle::P(const std::string& name) const {
+    auto it = pidx.find(name);
+    DSD_CHECK(it != pidx.end(), "unknown parameter %s", name.c_str());
+    return reinterpret_cast<float*>(slab + params[it->second].off);
+}
+const Param& dsd_handle::PP(const std::string& name) const {
+    auto it = pidx.find(name);
+    DSD_CHECK(it != pidx.end(), "unknown parameter %s", name.c_str());
+    return params[it->second];
+}
+
+void dsd::net_declare_params(dsd_handle* h) {
+    if (!h->is_block) {
+        const Spec s = build_spec(h->cfg);
+        const bool film = h->cfg.use_scale_shift_norm;
+        p_lin(h, "time_embed.0", h->cfg.model_channels, s.ted);
+        p_lin(h, "time_embed.2", s.ted, s.ted);
+        for (const char* sfx : {"", "_a", "_al", "_l"})
+            for (size_t bi = 0; bi < s.input_blocks.size(); ++bi)
+                for (size_t li = 0; li < s.input_blocks[bi].size(); ++li)
+                    p_layer(h, "input_blocks" + std::string(sfx) + "." + std::to_string(bi) + "." + std::to_string(li),
+                            s.input_blocks[bi][li], s.ted, film);
+        for (size_t li = 0; li < s.middle.size(); ++li) p_layer(h, "middle_block." + std::to_string(li), s.middle[li], s.ted, film);
+        for (size_t bi = 0; bi < s.output_blocks.size(); ++bi)
+            for (size_t li = 0; li < s.output_blocks[bi].size(); ++li)
+                p_layer(h, "output_blocks." + std::to_string(bi) + "." + std::to_string(li), s.output_blocks[bi][li], s.ted, film);
+        p_norm(h, "out.0", s.final_ch);
+        p_conv(h, "out.2", h->cfg.model_channels, h->cfg.out_channels, 3);
+        for (const char* nm : {"conv_style", "conv_content", "conv_anatomy", "conv_lesion"}) p_disentangle(h, nm, s.conv_ch, s.half);
+        for (const char* nm : {"style_proj", "share_content_proj", "anatomy_proj", "lesion_proj"}) {
+            p_lin(h, std::string(nm) + ".0.se.0", s.half, s.half / 8, false);
+            p_lin(h, std::string(nm) + ".0.se.2", s.half / 8, s.half, false);
+            p_conv(h, std::string(nm) + ".1", s.half, s.half, 3);
+        }
+        p_conv(h, "all_proj.1", s.half * 6, s.conv_ch, 1);
+    } else {
+        const auto& a = h->iargs;
+        auto need = [&](size_t n) { DSD_CHECK(a.size() >= n, "block kind %d needs %zu integer arguments", h->block_kind, n); };
+        switch (h->block_kind) {
+            case DSD_BLOCK_RES: need(6); p_res(h, "", a[0], a[1], a[2], a[3] != 0, false); break;
+            case DSD_BLOCK_ATTN: need(3); p_attn(h, "", a[0]); break;
+            case DSD_BLOCK_UPSAMPLE: need(1); p_conv(h, "conv", a[0], a[0], 3); break;
+            case DSD_BLOCK_DOWNSAMPLE: need(1); p_conv(h, "op", a[0], a[0], 3); break;
+            case DSD_BLOCK_DISENTANGLE: need(2); p_disentangle(h, "", a[0], a[1]); break;
+            case DSD_BLOCK_SE:
+                need(2);
+                p_lin(h, "se.0", a[0], a[0] / a[1], false);
+                p_lin(h, "se.2", a[0] / a[1], a[0], false);
+                break;
+            case DSD_BLOCK_CROSSATTN: need(4); p_xattn(h, "", a[0], a[1], a[2], a[3]); break;
+            case DSD_BLOCK_FF_GEGLU: need(2); p_ff(h, "", a[0], a[1]); break;
+            case DSD_BLOCK_BASIC_TRANSFORMER: need(4); p_btb(h, "", a[0], a[1], a[2], a[3]); break;
+            case DSD_BLOCK_SPATIAL_TRANSFORMER: {
+                need(6);
+                const int inner = a[1] * a[2];
+                p_norm(h, "norm", a[0]);
+                if (a[5]) p_lin(h, "proj_in", a[0], inner); else p_conv(h, "proj_in", a[0], inner, 1);
+                for (int d = 0; d < a[3]; ++d) p_btb(h, "transformer_blocks." + std::to_string(d), inner, a[1], a[2], a[4]);
+                if (a[5]) p_lin(h, "proj_out", a[0], inner); else p_conv(h, "proj_out", inner, a[0], 1);
+                break;
+            }
+            default: fail("unknown block kind %d", h->block_kind);
+        }
+        // block parameter names carry no leading '.'
+        for (auto& p : h->params)
+            if (!p.name.empty() && p.name[0] == '.') p.name = p.name.substr(1);
+        h->pidx.clear();
+        for (size_t i = 0; i < h->params.size(); ++i) h->pidx[h->params[i].name] = (int)i;
+    }
+    // lay the slab out: general region, then the contiguous emb_layers weight and bias regions
+    size_t off = 0;
+    for (int region = 0; region < 3; ++region) {
+        if (region == 1) h->emb_w_off = off;
+        if (region == 2) h->emb_b_off = off;
+        for (auto& p : h->params) {
+            if (p.region != region) continue;
+            p.off = off;
+            size_t b = (size_t)p.numel * sizeof(float);
+            if (region == 0) b = (b + 255) & ~(size_t)255;  // emb regions stay densely packed (one GEMM over all of them)
+            off += b;
+            if (region == 2) h->emb_total += p.numel;
+        }
+        off = (off + 255) & ~(size_t)255;
+    }
+    h->slab_bytes = off + 256;
+    DSD_HIP(hipMalloc((void**)&h->slab, h->slab_bytes));
+}
+
+void dsd::net_set_param(dsd_handle* h, const char* name, const float* src, const int64_t* shape, int ndim, int src_is_device,
+                        hipStream_t s) {
+    auto it = h->pidx.find(name);
+    DSD_CHECK(it != h->pidx.end(), "unexpected parameter '%s'", name);
+    Param& p = h->params[it->second];
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    bool same = (int)p.shape.size() == ndim;
+    for (int i = 0; same && i < ndim; ++i) same = p.shape[i] == shape[i];
+    // a Linear weight [O,I] may also arrive as a 1x1 conv weight [O,I,1,1] / [O,I,1] and vice versa
+    if (!same && n == p.numel && ndim >= 2 && p.shape.size() >= 2 && shape[0] == p.shape[0] && shape[1] == p.shape[1]) same = true;
+    if (!same) {
+        std::string want, got;
+        for (auto d : p.shape) want += std::to_string(d) + ",";
+        for (int i = 0; i < ndim; ++i) got += std::to_string(shape[i]) + ",";
+        fail("size mismatch for %s: expected [%s] got [%s]", name, want.c_str(), got.c_str());
+    }
+    float* dst = reinterpret_cast<float*>(h->slab + p.off);
+    const size_t bytes = (size_t)p.numel * sizeof(float);
+    const hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (p.pack3x3) {
+        if (h->staging_bytes < bytes) {
+            if (h->staging) {
+                DSD_HIP(hipStreamSynchronize(s));
+                DSD_HIP(hipFree(h->staging));
+            }
+            h->staging_bytes = std::max(bytes, (size_t)64 << 20);
+            DSD_HIP(hipMalloc((void**)&h->staging, h->staging_bytes));
+        }
+        DSD_HIP(hipMemcpyAsync(h->staging, src, bytes, kind, s));
+        pack_ohwi(h->staging, dst, (int)p.shape[0], (int)p.shape[1], 3, s);
+        if (!src_is_device) DSD_HIP(hipStreamSynchronize(s));  // the caller may free/reuse its host buffer
+    } else {
+        DSD_HIP(hipMemcpyAsync(dst, src, bytes, kind, s));
+        if (!src_is_device) DSD_HIP(hipStreamSynchronize(s));
+    }
+    p.set = true;
+}
+
+void dsd::net_free(dsd_handle* h) {
+    if (h->slab) hipFree(h->slab);
+    if (h->staging) hipFree(h->staging);
+    if (h->arena) hipFree(h->arena);
+    if (h->tbuf) hipFree(h->tbuf);
+    if (h->mout) hipFree(h->mout);
+    if (h->zplane) hipFree(h->zplane);
+}
+
+// =============================================================================================== builder
+namespace {
+
+struct EmbRef {
+    size_t arena_off = 0;  // emb_all tensor
+    int64_t col = 0;       // first column of this block
+    int stride = 0;
+    bool valid = false;
+};
+
+struct Builder {
+    dsd_handle* hd;
+    Plan& plan;
+    ArenaPlanner ar;
+    int B;
+    Builder(dsd_handle* h, Plan& p, int b) : hd(h), plan(p), B(b) {}
+
+    Tn alloc(int n, int h, int w, int c) {
+        Tn t;
+        t.n = n; t.h = h; t.w = w; t.c = c;
+        t.off = ar.alloc(t.bytes());
+        return t;
+    }
+    void release(Tn& t) {
+        if (t.valid()) ar.release(t.off, t.bytes());
+        t.off = (size_t)-1;
+    }
+    size_t alloc_raw(size_t bytes) { return ar.alloc(bytes); }
+    void release_raw(size_t off, size_t bytes) { ar.release(off, bytes); }
+    void op(std::function<void(hipStream_t)> f, int launches = 1) {
+        plan.ops.push_back(std::move(f));
+        plan.launches += launches;
+    }
+    float* W(const std::string& n) { return hd->P(n); }
+    bool has(const std::string& n) { return hd->pidx.count(n) != 0; }
+
+    // ---- convolution: src is an arena tensor, or (plane >= 0) one of the caller's input planes
+    Tn conv(const std::string& name, const Tn& x, int cout, int ks, int stride = 1, bool ups = false,
+            const EmbRef* emb = nullptr, const Tn* res = nullptr, int plane = -1, bool to_out = false, bool bias = true) {
+        ConvArgs a;
+        a.N = x.n; a.H = x.h; a.W = x.w; a.Cin = x.c; a.Cout = cout; a.ks = ks; a.stride = stride; a.ups = ups ? 1 : 0;
+        a.w = W(name + ".weight");
+        a.bias = bias ? W(name + ".bias") : nullptr;
+        const Param& pw = hd->PP(name + ".weight");
+        DSD_CHECK(pw.numel == (int64_t)cout * x.c * ks * ks, "conv %s: weight has %lld elements, graph expects %dx%dx%dx%d",
+                  name.c_str(), (long long)pw.numel, cout, x.c, ks, ks);
+        const int IHg = ups ? x.h * 2 : x.h, IWg = ups ? x.w * 2 : x.w, pad = ks / 2;
+        const int OH = (IHg + 2 * pad - ks) / stride + 1, OW = (IWg + 2 * pad - ks) / stride + 1;
+        Tn y;
+        if (!to_out) y = alloc(x.n, OH, OW, cout);
+        if (res) DSD_CHECK(res->n == x.n && res->h == OH && res->w == OW && res->c == cout, "conv %s: residual shape mismatch", name.c_str());
+        const size_t xoff = x.off, yoff = y.off, roff = res ? res->off : 0;
+        const bool has_res = res != nullptr;
+        EmbRef e;
+        if (emb) e = *emb;
+        dsd_handle* h = hd;
+        const bool nchw = to_out && cout > 1;
+        plan.flops += conv2d_flops(a);
+        op([=](hipStream_t s) {
+            ConvArgs c = a;
+            if (plane >= 0) {
+                c.x = h->io.plane[plane];
+                c.x_bs = h->io.plane_bs[plane];
+            } else {
+                c.x = reinterpret_cast<const float*>(h->arena + xoff);
+                c.x_bs = -1;
+            }
+            c.y = to_out ? h->io.out : reinterpret_cast<float*>(h->arena + yoff);
+            c.out_nchw = nchw ? 1 : 0;
+            if (e.valid) {
+                c.emb = reinterpret_cast<const float*>(h->arena + e.arena_off) + e.col;
+                c.emb_stride = e.stride;
+            }
+            if (has_res) c.res = reinterpret_cast<const float*>(h->arena + roff);
+            conv2d(c, s);
+        });
+        return y;
+    }
+
+    // ---- GroupNorm32 (+SiLU, + FiLM) : stats, finalize, apply
+    Tn gn_act(const std::string& name, const Tn& x, int act, float eps = 1e-5f, const EmbRef* film = nullptr) {
+        const int HW = x.hw(), C = x.c, N = x.n;
+        const int nchunk = gn_nchunks(HW, C);
+        const size_t pbytes = (size_t)N * nchunk * 32 * 2 * sizeof(double);
+        const size_t sbytes = (size_t)N * C * sizeof(float);
+        const size_t poff = alloc_raw(pbytes), scoff = alloc_raw(sbytes), shoff = alloc_raw(sbytes);
+        Tn y = alloc(x.n, x.h, x.w, x.c);
+        const float* gamma = W(name + ".weight");
+        const float* beta = W(name + ".bias");
+        DSD_CHECK(hd->PP(name + ".weight").numel == C, "norm %s: %lld channels, graph expects %d", name.c_str(),
+                  (long long)hd->PP(name + ".weight").numel, C);
+        const size_t xoff = x.off, yoff = y.off;
+        EmbRef e;
+        if (film) e = *film;
+        dsd_handle* h = hd;
+        op([=](hipStream_t s) {
+            const float* xp = reinterpret_cast<const float*>(h->arena + xoff);
+            double* part = reinterpret_cast<double*>(h->arena + poff);
+            float* sc = reinterpret_cast<float*>(h->arena + scoff);
+            float* sh = reinterpret_cast<float*>(h->arena + shoff);
+            gn_stats(xp, N, HW, C, part, nchunk, s);
+            const float* fp = e.valid ? reinterpret_cast<const float*>(h->arena + e.arena_off) + e.col : nullptr;
+            gn_finalize(part, nchunk, N, HW, C, gamma, beta, eps, fp, e.stride, sc, sh, s);
+            affine_act(xp, N, HW, C, sc, sh, act, reinterpret_cast<float*>(h->arena + yoff), s);
+        }, 3);
+        release_raw(poff, pbytes);
+        release_raw(scoff, sbytes);
+        release_raw(shoff, sbytes);
+        return y;
+    }
+
+    Tn resample(const Tn& x, bool up) {
+        Tn y = up ? alloc(x.n, x.h * 2, x.w * 2, x.c) : alloc(x.n, x.h / 2, x.w / 2, x.c);
+        const size_t xoff = x.off, yoff = y.off;
+        dsd_handle* h = hd;
+        const Tn xx = x;
+        op([=](hipStream_t s) {
+            const float* xp = reinterpret_cast<const float*>(h->arena + xoff);
+            float* yp = reinterpret_cast<float*>(h->arena + yoff);
+            if (up) upsample2(xp, xx.n, xx.h, xx.w, xx.c, yp, s); else avgpool2(xp, xx.n, xx.h, xx.w, xx.c, yp, s);
+        });
+        return y;
+    }
+
+    // ResBlock._forward, openaimodel.py:264-284.  x stays owned by the caller.
+    Tn res_block(const std::string& p, const Tn& x, int cin, int cout, bool up, bool down, const EmbRef& emb) {
+        DSD_CHECK(x.c == cin, "ResBlock %s: input has %d channels, expected %d", p.c_str(), x.c, cin);
+        const bool film = hd->PP(pre(p, "emb_layers.1.weight")).shape[0] == 2 * cout;
+        Tn a = gn_act(pre(p, "in_layers.0"), x, ACT_SILU);
+        Tn xs = x;
+        bool xs_owned = false;
+        if (up || down) {
+            Tn a2 = resample(a, up);
+            release(a);
+            a = a2;
+            xs = resample(x, up);
+            xs_owned = true;
+        }
+        Tn h = conv(pre(p, "in_layers.2"), a, cout, 3, 1, false, film ? nullptr : &emb);
+        release(a);
+        Tn a3 = gn_act(pre(p, "out_layers.0"), h, ACT_SILU, 1e-5f, film ? &emb : nullptr);
+        release(h);
+        Tn skip = xs;
+        bool skip_owned = false;
+        if (cin != cout) {
+            skip = conv(pre(p, "skip_connection"), xs, cout, 1);
+            skip_owned = true;
+        }
+        Tn out = conv(pre(p, "out_layers.3"), a3, cout, 3, 1, false, nullptr, &skip);
+        release(a3);
+        if (skip_owned) release(skip);
+        if (xs_owned) release(xs);
+        return out;
+    }
+
+    // AttentionBlock._forward, openaimodel.py:467-473
+    Tn attn_block(const std::string& p, const Tn& x, int heads, bool new_order) {
+        const int C = x.c, T = x.hw();
+        DSD_CHECK(C % heads == 0, "attention %s: %d channels not divisible by %d heads", p.c_str(), C, heads);
+        const int d = C / heads;
+        Tn n = gn_act(pre(p, "norm"), x, ACT_NONE);
+        Tn qkv = conv(pre(p, "qkv"), n, 3 * C, 1);
+        release(n);
+        Tn a = alloc(x.n, x.h, x.w, C);
+        {
+            AttnArgs aa;
+            aa.N = x.n; aa.Tq = T; aa.Tk = T; aa.heads = heads; aa.d = d;
+            aa.ldq = aa.ldk = aa.ldv = 3 * C; aa.ldo = C;
+            const float scale = 1.f / std::sqrt(std::sqrt((float)d));  // openaimodel.py:547
+            aa.scale_q = aa.scale_k = scale;
+            int qo, ko, vo;
+            if (new_order) {  // QKVAttention: qkv.chunk(3) then heads
+                qo = 0; ko = C; vo = 2 * C;
+                aa.q_hs = aa.k_hs = aa.v_hs = d;
+            } else {          // QKVAttentionLegacy: heads then split(ch)
+                qo = 0; ko = d; vo = 2 * d;
+                aa.q_hs = aa.k_hs = aa.v_hs = 3 * d;
+            }
+            const size_t qoff = qkv.off, aoff = a.off;
+            dsd_handle* h = hd;
+            plan.flops += 4.0 * x.n * heads * (double)T * T * d;
+            op([=](hipStream_t s) {
+                AttnArgs r = aa;
+                const float* base = reinterpret_cast<const float*>(h->arena + qoff);
+                r.q = base + qo; r.k = base + ko; r.v = base + vo;
+                r.out = reinterpret_cast<float*>(h->arena + aoff);
+                attention(r, s);
+            });
+        }
+        release(qkv);
+        Tn out = conv(pre(p, "proj_out"), a, C, 1, 1, false, nullptr, &x);
+        release(a);
+        return out;
+    }
+
+    // FeatureDisentangle.forward, model.py:165-168
+    Tn disentangle(const std::string& p, const Tn& x, int half) {
+        Tn a = gn_act(pre(p, "conv_1.0"), x, ACT_SILU);
+        Tn o = conv(pre(p, "conv_1.2"), a, x.c, 3, 1, false, nullptr, &x);
+        release(a);
+        Tn a2 = gn_act(pre(p, "conv_2.0"), o, ACT_SILU);
+        release(o);
+        Tn y = conv(pre(p, "conv_2.2"), a2, half, 1);
+        release(a2);
+        return y;
+    }
+
+    Tn se(const std::string& p, const Tn& x) {
+        Tn y = alloc(x.n, x.h, x.w, x.c);
+        const float* w1 = W(pre(p, "se.0.weight"));
+        const float* w2 = W(pre(p, "se.2.weight"));
+        const int Cr = (int)hd->PP(pre(p, "se.0.weight")).shape[0];
+        const size_t xoff = x.off, yoff = y.off;
+        const Tn xx = x;
+        dsd_handle* h = hd;
+        op([=](hipStream_t s) {
+            se_scale(reinterpret_cast<const float*>(h->arena + xoff), xx.n, xx.hw(), xx.c, w1, w2, Cr,
+                     reinterpret_cast<float*>(h->arena + yoff), s);
+        });
+        return y;
+    }
+
+    // dst[:, coff:coff+C] = act((a+b+c+d)/div)
+    void avg(const Tn* srcs, int nsrc, float div, const Tn& dst, int coff, int act) {
+        size_t o[4] = {0, 0, 0, 0};
+        for (int i = 0; i < nsrc; ++i) o[i] = srcs[i].off;
+        const int C = srcs[0].c;
+        const int64_t pixels = (int64_t)srcs[0].n * srcs[0].hw();
+        const size_t doff = dst.off;
+        const int dstC = dst.c;
+        dsd_handle* h = hd;
+        op([=](hipStream_t s) {
+            const float* p[4] = {nullptr, nullptr, nullptr, nullptr};
+            for (int i = 0; i < nsrc; ++i) p[i] = reinterpret_cast<const float*>(h->arena + o[i]);
+            avg_into(p[0], p[1], p[2], p[3], div, pixels, C, reinterpret_cast<float*>(h->arena + doff), dstC, coff, act, s);
+        });
+    }
+
+    // TimestepEmbedSequential.forward, openaimodel.py:80-90.  Consumes (releases) x unless keep_input.
+    Tn block(const std::string& prefix, const std::vector<Layer>& layers, Tn x, bool keep_input,
+             const std::vector<EmbRef>& embs, size_t& emb_i, int plane = -1) {
+        Tn cur = x;
+        bool cur_owned = !keep_input;
+        for (size_t li = 0; li < layers.size(); ++li) {
+            const Layer& L = layers[li];
+            const std::string nm = prefix + "." + std::to_string(li);
+            Tn nxt;
+            switch (L.kind) {
+                case L_CONV: nxt = conv(nm, cur, L.cout, 3, 1, false, nullptr, nullptr, plane); break;
+                case L_RES: nxt = res_block(nm, cur, L.cin, L.cout, L.up, L.down, embs.at(emb_i++)); break;
+                case L_ATTN: nxt = attn_block(nm, cur, L.heads, hd->cfg.use_new_attention_order != 0); break;
+                case L_DOWN: nxt = conv(nm + ".op", cur, L.ch, 3, 2); break;
+                case L_UP: nxt = conv(nm + ".conv", cur, L.ch, 3, 1, true); break;
+            }
+            if (cur_owned && plane < 0) release(cur);
+            plane = -1;
+            cur = nxt;
+            cur_owned = true;
+        }
+        return cur;
+    }
+
+    // ---------------------------------------------------------------- token blocks (cross-attention variant)
+    Tn linear_tok(const std::string& name, const Tn& x, int cout, bool bias, const Tn* res = nullptr) {
+        return conv(name, x, cout, 1, 1, false, nullptr, res, -1, false, bias);
+    }
+    Tn lnorm(const std::string& name, const Tn& x) {
+        Tn y = alloc(x.n, x.h, x.w, x.c);
+        const float* g = W(name + ".weight");
+        const float* b = W(name + ".bias");
+        const size_t xoff = x.off, yoff = y.off;
+        const int64_t rows = (int64_t)x.n * x.hw();
+        const int C = x.c;
+        dsd_handle* h = hd;
+        op([=](hipStream_t s) {
+            layer_norm(reinterpret_cast<const float*>(h->arena + xoff), rows, C, g, b, 1e-5f,
+                       reinterpret_cast<float*>(h->arena + yoff), s);
+        });
+        return y;
+    }
+    // CrossAttention.forward (attention.py:164-193); ctx == nullptr -> self attention.  + res if given.
+    Tn xattn(const std::string& p, const Tn& x, const Tn* ctx, int heads, const Tn* res) {
+        const Tn& c = ctx ? *ctx : x;
+        const int inner = (int)hd->PP(pre(p, "to_q.weight")).shape[0];
+        const int d = inner / heads;
+        Tn q = linear_tok(pre(p, "to_q"), x, inner, false);
+        Tn k = linear_tok(pre(p, "to_k"), c, inner, false);
+        Tn v = linear_tok(pre(p, "to_v"), c, inner, false);
+        Tn a = alloc(x.n, x.h, x.w, inner);
+        AttnArgs aa;
+        aa.N = x.n; aa.Tq = x.hw(); aa.Tk = c.hw(); aa.heads = heads; aa.d = d;
+        aa.ldq = aa.ldk = aa.ldv = aa.ldo = inner;
+        aa.q_hs = aa.k_hs = aa.v_hs = d;
+        aa.scale_s = 1.f / std::sqrt((float)d);
+        const size_t qo = q.off, ko = k.off, vo = v.off, ao = a.off;
+        dsd_handle* h = hd;
+        plan.flops += 4.0 * x.n * heads * (double)aa.Tq * aa.Tk * d;
+        op([=](hipStream_t s) {
+            AttnArgs r = aa;
+            r.q = reinterpret_cast<const float*>(h->arena + qo);
+            r.k = reinterpret_cast<const float*>(h->arena + ko);
+            r.v = reinterpret_cast<const float*>(h->arena + vo);
+            r.out = reinterpret_cast<float*>(h->arena + ao);
+            attention(r, s);
+        });
+        release(q); release(k); release(v);
+        Tn y = linear_tok(pre(p, "to_out.0"), a, x.c, true, res);
+        release(a);
+        return y;
+    }
+    Tn ff_geglu(const std::string& p, const Tn& x, const Tn* res) {
+        const int inner2 = (int)hd->PP(pre(p, "net.0.proj.weight")).shape[0];
+        Tn hh = linear_tok(pre(p, "net.0.proj"), x, inner2, true);
+        Tn g = alloc(x.n, x.h, x.w, inner2 / 2);
+        const size_t ho = hh.off, go = g.off;
+        const int64_t rows = (int64_t)x.n * x.hw();
+        dsd_handle* h = hd;
+        op([=](hipStream_t s) {
+            geglu(reinterpret_cast<const float*>(h->arena + ho), rows, inner2 / 2, reinterpret_cast<float*>(h->arena + go), s);
+        });
+        release(hh);
+        Tn y = linear_tok(pre(p, "net.2"), g, x.c, true, res);
+        release(g);
+        return y;
+    }
+    // BasicTransformerBlock._forward (attention.py:326-330); x stays owned by the caller
+    Tn btb(const std::string& p, const Tn& x, const Tn* ctx, int heads) {
+        Tn n1 = lnorm(pre(p, "norm1"), x);
+        Tn x1 = xattn(pre(p, "attn1"), n1, nullptr, heads, &x);
+        release(n1);
+        Tn n2 = lnorm(pre(p, "norm2"), x1);
+        Tn x2 = xattn(pre(p, "attn2"), n2, ctx, heads, &x1);
+        release(n2); release(x1);
+        Tn n3 = lnorm(pre(p, "norm3"), x2);
+        Tn x3 = ff_geglu(pre(p, "ff"), n3, &x2);
+        release(n3); release(x2);
+        return x3;
+    }
+
+    // copy an external device buffer (io.*) into the arena, optionally NCHW -> NHWC
+    Tn import_ext(int which, int n, int h, int w, int c, bool from_nchw) {
+        Tn t = alloc(n, h, w, c);
+        const size_t off = t.off;
+        dsd_handle* hh = hd;
+        op([=](hipStream_t s) {
+            const float* src = which == 0 ? hh->io.x_nchw : (which == 1 ? hh->io.aux : hh->io.aux2);
+            float* dst = reinterpret_cast<float*>(hh->arena + off);
+            if (from_nchw && c > 1 && h * w > 1)
+                nchw_to_nhwc(src, n, c, h * w, dst, s);
+            else
+                DSD_HIP(hipMemcpyAsync(dst, src, (size_t)n * h * w * c * sizeof(float), hipMemcpyDeviceToDevice, s));
+        });
+        return t;
+    }
+    void export_out(const Tn& t, bool to_nchw, int feat_idx = -1) {
+        const size_t off = t.off;
+        const Tn tt = t;
+        dsd_handle* hh = hd;
+        op([=](hipStream_t s) {
+            float* dst = feat_idx >= 0 ? hh->io.feats[feat_idx] : hh->io.out;
+            const float* src = reinterpret_cast<const float*>(hh->arena + off);
+            if (to_nchw && tt.c > 1 && tt.hw() > 1)
+                nhwc_to_nchw(src, tt.n, tt.c, tt.hw(), dst, s);
+            else
+                DSD_HIP(hipMemcpyAsync(dst, src, tt.bytes(), hipMemcpyDeviceToDevice, s));
+        });
+    }
+};
+
+// --------------------------------------------------------------------------------- DSUnetModel.forward
+void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats) {
+    dsd_handle* hd = b.hd;
+    const dsd_config& cfg = hd->cfg;
+    const Spec sp = build_spec(cfg);
+    const int B = b.B;
+    const int nds = cfg.n_levels - 1;
+    DSD_CHECK(H % (1 << nds) == 0 && W % (1 << nds) == 0, "H=%d, W=%d must be multiples of %d (down/up-sampling + skip concat)", H, W, 1 << nds);
+    (void)zero_al_l;
+
+    // ---- timestep embedding MLP + all 68 emb_layers as ONE GEMM (model.py:645-646; openaimodel.py:222-228,273)
+    const int mc = cfg.model_channels, ted = sp.ted;
+    Tn temb = b.alloc(B, 1, 1, mc), e1 = b.alloc(B, 1, 1, ted), emb = b.alloc(B, 1, 1, ted);
+    Tn emb_all = b.alloc(B, 1, 1, (int)hd->emb_total);
+    {
+        const size_t to = temb.off, e1o = e1.off, eo = emb.off, ao = emb_all.off;
+        const float *w0 = b.W("time_embed.0.weight"), *b0 = b.W("time_embed.0.bias");
+        const float *w2 = b.W("time_embed.2.weight"), *b2 = b.W("time_embed.2.bias");
+        const float* wall = reinterpret_cast<const float*>(hd->slab + hd->emb_w_off);
+        const float* ball = reinterpret_cast<const float*>(hd->slab + hd->emb_b_off);
+        const int etot = (int)hd->emb_total;
+        b.plan.flops += 2.0 * B * ((double)mc * ted + (double)ted * ted + (double)ted * etot);
+        b.op([=](hipStream_t s) {
+            float* tp = reinterpret_cast<float*>(hd->arena + to);
+            float* e1p = reinterpret_cast<float*>(hd->arena + e1o);
+            float* ep = reinterpret_cast<float*>(hd->arena + eo);
+            float* ap = reinterpret_cast<float*>(hd->arena + ao);
+            timestep_embedding(hd->io.t, hd->io.t_is_float, B, mc, tp, s);
+            linear(tp, B, mc, mc, w0, b0, ted, ACT_NONE, e1p, ted, s);
+            linear(e1p, B, ted, ted, w2, b2, ted, ACT_SILU, ep, ted, s);
+            linear(ep, B, ted, ted, wall, ball, etot, ACT_SILU, ap, etot, s);
+        }, 4);
+    }
+    b.release(temb); b.release(e1); b.release(emb);
+    // column of each ResBlock inside emb_all = position of its bias in the contiguous bias region (declaration order)
+    std::unordered_map<std::string, int64_t> emb_col;
+    {
+        int64_t col = 0;
+        for (const auto& p : hd->params)
+            if (p.region == 2) {
+                emb_col[p.name.substr(0, p.name.size() - std::strlen(".emb_layers.1.bias"))] = col;
+                col += p.numel;
+            }
+    }
+    auto embs_for = [&](const std::string& prefix, const std::vector<std::vector<Layer>>& blocks) {
+        std::vector<std::vector<EmbRef>> out(blocks.size());
+        for (size_t bi = 0; bi < blocks.size(); ++bi)
+            for (size_t li = 0; li < blocks[bi].size(); ++li)
+                if (blocks[bi][li].kind == L_RES) {
+                    EmbRef e;
+                    e.arena_off = emb_all.off;
+                    e.col = emb_col.at(prefix + "." + std::to_string(bi) + "." + std::to_string(li));
+                    e.stride = (int)hd->emb_total;
+                    e.valid = true;
+                    out[bi].push_back(e);
+                }
+        return out;
+    };
+
+    // ---- four encoder streams (model.py:674-686): stream order n, a, al, l ; planes io.plane[0..3]
+    const char* sfx[4] = {"", "_a", "_al", "_l"};
+    std::vector<Tn> hs[4];
+    for (int s = 0; s < 4; ++s) {
+        const std::string base = std::string("input_blocks") + sfx[s];
+        auto embs = embs_for(base, sp.input_blocks);
+        Tn cur;
+        cur.n = B; cur.h = H; cur.w = W; cur.c = 1;  // the caller's plane
+        for (size_t bi = 0; bi < sp.input_blocks.size(); ++bi) {
+            size_t ei = 0;
+            Tn nxt = b.block(base + "." + std::to_string(bi), sp.input_blocks[bi], cur, /*keep_input=*/true, embs[bi], ei,
+                             bi == 0 ? s : -1);
+            hs[s].push_back(nxt);
+            cur = nxt;
+        }
+    }
+    // ---- middle block on the noise stream only (model.py:688)
+    Tn h_n;
+    {
+        std::vector<EmbRef> me;
+        for (size_t li = 0; li < sp.middle.size(); ++li)
+            if (sp.middle[li].kind == L_RES) {
+                EmbRef e;
+                e.arena_off = emb_all.off;
+                e.col = emb_col.at("middle_block." + std::to_string(li));
+                e.stride = (int)hd->emb_total;
+                e.valid = true;
+                me.push_back(e);
+            }
+        size_t ei = 0;
+        h_n = b.block("middle_block", sp.middle, hs[0].back(), /*keep_input=*/true, me, ei);
+    }
+    // ---- disentangle heads (model.py:695-725)
+    const Tn &h_a = hs[1].back(), &h_al = hs[2].back(), &h_l = hs[3].back();
+    const int half = sp.half;
+    Tn st[3] = {b.disentangle("conv_style", h_a, half), b.disentangle("conv_style", h_al, half), b.disentangle("conv_style", h_l, half)};
+    Tn ct[3] = {b.disentangle("conv_content", h_a, half), b.disentangle("conv_content", h_al, half), b.disentangle("conv_content", h_l, half)};
+    Tn an[2] = {b.disentangle("conv_anatomy", h_a, half), b.disentangle("conv_anatomy", h_al, half)};
+    Tn le[2] = {b.disentangle("conv_lesion", h_al, half), b.disentangle("conv_lesion", h_l, half)};
+    Tn n_style, n_content;
+    if (want_feats) {  // dead for sampling: only returned in the dict (model.py:695-696,729)
+        n_style = b.disentangle("conv_style", h_n, half);
+        n_content = b.disentangle("conv_content", h_n, half);
+    }
+    auto proj = [&](const std::string& nm, Tn* list, int n) {
+        Tn m = b.alloc(B, list[0].h, list[0].w, half);
+        b.avg(list, n, (float)n, m, 0, ACT_NONE);           // ht.mean(ht.stack(list), dim=0)
+        Tn se = b.se(nm + ".0", m);
+        b.release(m);
+        Tn y = b.conv(nm + ".1", se, half, 3);
+        b.release(se);
+        return y;
+    };
+    Tn h_style = proj("style_proj", st, 3);
+    Tn h_share = proj("share_content_proj", ct, 3);
+    Tn h_anat = proj("anatomy_proj", an, 2);
+    Tn h_les = proj("lesion_proj", le, 2);
+    if (want_feats) {
+        int fi = 0;
+        for (int i = 0; i < 3; ++i) b.export_out(st[i], true, fi++);
+        for (int i = 0; i < 3; ++i) b.export_out(ct[i], true, fi++);
+        for (int i = 0; i < 2; ++i) b.export_out(an[i], true, fi++);
+        for (int i = 0; i < 2; ++i) b.export_out(le[i], true, fi++);
+        b.export_out(h_style, true, fi++);
+        b.export_out(n_style, true, fi++);
+        b.export_out(h_share, true, fi++);
+        b.export_out(n_content, true, fi++);
+        b.release(n_style); b.release(n_content);
+    }
+    for (auto& t : st) b.release(t);
+    for (auto& t : ct) b.release(t);
+    for (auto& t : an) b.release(t);
+    for (auto& t : le) b.release(t);
+    // ---- h = all_proj(cat[h_n, share_content, style, anatomy, lesion])  (model.py:734-738): SiLU fused into the concat
+    Tn cat = b.alloc(B, h_n.h, h_n.w, sp.conv_ch + 4 * half);
+    b.avg(&h_n, 1, 1.f, cat, 0, ACT_SILU);
+    b.avg(&h_share, 1, 1.f, cat, sp.conv_ch, ACT_SILU);
+    b.avg(&h_style, 1, 1.f, cat, sp.conv_ch + half, ACT_SILU);
+    b.avg(&h_anat, 1, 1.f, cat, sp.conv_ch + 2 * half, ACT_SILU);
+    b.avg(&h_les, 1, 1.f, cat, sp.conv_ch + 3 * half, ACT_SILU);
+    b.release(h_n); b.release(h_share); b.release(h_style); b.release(h_anat); b.release(h_les);
+    Tn h = b.conv("all_proj.1", cat, sp.conv_ch, 1);
+    b.release(cat);
+    // ---- decoder (model.py:743-746): cat[h, (hs+hs_a+hs_al+hs_l)/4]
+    auto dembs = embs_for("output_blocks", sp.output_blocks);
+    for (size_t bi = 0; bi < sp.output_blocks.size(); ++bi) {
+        Tn sk[4];
+        for (int s = 0; s < 4; ++s) {
+            sk[s] = hs[s].back();
+            hs[s].pop_back();
+        }
+        Tn c2 = b.alloc(B, h.h, h.w, h.c + sk[0].c);
+        DSD_CHECK(sk[0].h == h.h && sk[0].w == h.w, "decoder skip shape mismatch at output_blocks.%zu", bi);
+        b.avg(&h, 1, 1.f, c2, 0, ACT_NONE);
+        b.avg(sk, 4, 4.f, c2, h.c, ACT_NONE);
+        b.release(h);
+        for (auto& t : sk) b.release(t);
+        size_t ei = 0;
+        h = b.block("output_blocks." + std::to_string(bi), sp.output_blocks[bi], c2, /*keep_input=*/false, dembs[bi], ei);
+    }
+    // ---- out = Conv3x3(SiLU(GN(h)))  (model.py:511-515,751)
+    Tn a = b.gn_act("out.0", h, ACT_SILU);
+    b.release(h);
+    b.conv("out.2", a, cfg.out_channels, 3, 1, false, nullptr, nullptr, -1, /*to_out=*/true);
+    b.release(a);
+    b.release(emb_all);
+}
+
+// --------------------------------------------------------------------------------- single blocks
+void build_block(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
+    dsd_handle* hd = b.hd;
+    const auto& a = hd->iargs;
+    const int B = b.B;
+    const int kind = hd->block_kind;
+    const bool token = kind == DSD_BLOCK_CROSSATTN || kind == DSD_BLOCK_FF_GEGLU || kind == DSD_BLOCK_BASIC_TRANSFORMER;
+    Tn x = b.import_ext(0, B, H, W, C, !token);
+    Tn y;
+    switch (kind) {
+        case DSD_BLOCK_RES: {
+            DSD_CHECK(aux_len == a[2], "ResBlock: emb has %d channels, expected %d", aux_len, a[2]);
+            const int eo = (int)hd->PP("emb_layers.1.weight").shape[0];
+            Tn e = b.import_ext(1, B, 1, 1, aux_len, false);
+            Tn eout = b.alloc(B, 1, 1, eo);
+            const size_t ei = e.off, oo = eout.off;
+            const float *w = b.W("emb_layers.1.weight"), *bb = b.W("emb_layers.1.bias");
+            b.op([=](hipStream_t s) {
+                linear(reinterpret_cast<const float*>(hd->arena + ei), B, aux_len, aux_len, w, bb, eo, ACT_SILU,
+                       reinterpret_cast<float*>(hd->arena + oo), eo, s);
+            });
+            EmbRef er;
+            er.arena_off = eout.off; er.col = 0; er.stride = eo; er.valid = true;
+            y = b.res_block("", x, a[0], a[1], a[4] != 0, a[5] != 0, er);
+            b.release(e); b.release(eout);
+            break;
+        }
+        case DSD_BLOCK_ATTN: y = b.attn_block("", x, a[1], a[2] != 0); break;
+        case DSD_BLOCK_UPSAMPLE: y = b.conv("conv", x, a[0], 3, 1, true); break;
+        case DSD_BLOCK_DOWNSAMPLE: y = b.conv("op", x, a[0], 3, 2); break;
+        case DSD_BLOCK_DISENTANGLE: y = b.disentangle("", x, a[1]); break;
+        case DSD_BLOCK_SE: y = b.se("", x); break;
+        case DSD_BLOCK_CROSSATTN: {
+            Tn ctx;
+            if (aux_len > 0) ctx = b.import_ext(1, B, aux_len, 1, a[1], false);
+            y = b.xattn("", x, aux_len > 0 ? &ctx : nullptr, a[2], nullptr);
+            if (aux_len > 0) b.release(ctx);
+            break;
+        }
+        case DSD_BLOCK_FF_GEGLU: y = b.ff_geglu("", x, nullptr); break;
+        case DSD_BLOCK_BASIC_TRANSFORMER: {
+            Tn ctx;
+            if (aux_len > 0) ctx = b.import_ext(1, B, aux_len, 1, a[3], false);
+            y = b.btb("", x, aux_len > 0 ? &ctx : nullptr, a[1]);
+            if (aux_len > 0) b.release(ctx);
+            break;
+        }
+        case DSD_BLOCK_SPATIAL_TRANSFORMER: {
+            // attention.py:411-428; in NHWC the conv1x1 and Linear flavours of proj_in/proj_out are the same GEMM
+            const int inner = a[1] * a[2], depth = a[3];
+            DSD_CHECK(depth >= 1 && depth <= 2, "spatial transformer block handle supports depth 1..2 (two context inputs)");
+            Tn ctx[2];
+            if (aux_len > 0) ctx[0] = b.import_ext(1, B, aux_len, 1, a[4], false);
+            if (depth > 1 && aux_len2 > 0) ctx[1] = b.import_ext(2, B, aux_len2, 1, a[4], false);
+            Tn n = b.gn_act("norm", x, ACT_NONE, 1e-6f);
+            Tn t = b.conv("proj_in", n, inner, 1);
+            b.release(n);
+            for (int d = 0; d < depth; ++d) {
+                Tn t2 = b.btb("transformer_blocks." + std::to_string(d), t, ctx[d].valid() ? &ctx[d] : nullptr, a[1]);
+                b.release(t);
+                t = t2;
+            }
+            y = b.conv("proj_out", t, a[0], 1, 1, false, nullptr, &x);
+            b.release(t);
+            for (auto& c : ctx) b.release(c);
+            break;
+        }
+        default: fail("unknown block kind");
+    }
+    b.export_out(y, !token);
+    b.release(y);
+    b.release(x);
+}
+
+}  // namespace
+
+void dsd::net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int want_feats, int aux_len, int aux_len2) {
+    Plan& p = h->plan;
+    if (p.valid && p.B == B && p.C == C && p.H == H && p.W == W && p.zero_al_l == zero_al_l && p.want_feats == want_feats &&
+        p.aux_len == aux_len && p.aux_len2 == aux_len2)
+        return;
+    for (const auto& prm : h->params) DSD_CHECK(prm.set, "parameter '%s' has not been set", prm.name.c_str());
+    DSD_CHECK(B >= 1 && H >= 1 && W >= 1, "empty input");
+    p = Plan{};
+    p.B = B; p.C = C; p.H = H; p.W = W; p.zero_al_l = zero_al_l; p.want_feats = want_feats;
+    p.aux_len = aux_len; p.aux_len2 = aux_len2;
+    Builder b(h, p, B);
+    if (h->is_block)
+        build_block(b, C, H, W, aux_len, aux_len2);
+    else
+        build_unet(b, H, W, zero_al_l != 0, want_feats != 0);
+    p.arena_bytes = b.ar.peak + 256;
+    if (p.arena_bytes > h->arena_cap) {
+        DSD_HIP(hipDeviceSynchronize());
+        if (h->arena) DSD_HIP(hipFree(h->arena));
+        h->arena = nullptr;
+        h->arena_cap = 0;
+        DSD_HIP(hipMalloc((void**)&h->arena, p.arena_bytes));
+        h->arena_cap = p.arena_bytes;
+    }
+    p.valid = true;
+}
+
+void dsd::net_run(dsd_handle* h, hipStream_t s) {
+    DSD_CHECK(h->plan.valid, "no plan");
+    for (auto& f : h->plan.ops) f(s);
+}

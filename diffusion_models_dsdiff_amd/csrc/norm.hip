@@ -1,0 +1,246 @@
+// norm.hip — GroupNorm(32) statistics, affine+SiLU apply, LayerNorm.  HBM-bound kernels.
+//
+// Replaces GroupNorm32 (+ nn.SiLU) (ldm/modules/diffusionmodules/util.py:209-226; call sites
+// openaimodel.py:205-209,229-236,451; UNet_DS_Diff/model.py:155-163,511-513) and nn.LayerNorm in
+// ldm/modules/attention.py:316-318.
+//
+// NHWC: a group's channels are a short contiguous run per pixel, so the statistics pass streams whole
+// pixel rows with 16-byte loads (each thread owns fixed float4 columns -> per-channel fp64 partials in
+// registers), reduces channels -> groups through LDS in a fixed order (deterministic), and writes one
+// (sum, sumsq) fp64 pair per (sample, chunk, group).  gn_finalize folds mean/rstd/gamma/beta (and the
+// FiLM scale/shift of use_scale_shift_norm ResBlocks) into one per-(sample,channel) scale/shift pair,
+// so the apply pass is y = act(x*scale + shift): 1 read + 1 write of the tensor.
+#include "kernels.h"
+
+namespace dsd {
+
+static constexpr int GN_GROUPS = 32;
+
+struct GnGeom {
+    int threads;  // block size
+    int k;        // float4 columns per thread
+    int rpi;      // pixel rows per iteration
+    int ppc;      // pixels per chunk
+    int nchunk;
+};
+
+static GnGeom gn_geom(int HW, int C) {
+    GnGeom g{};
+    const int cols = C / 4;
+    if (cols <= 256) {
+        g.k = 1;
+        g.rpi = 256 / cols;
+        g.threads = g.rpi * cols;
+    } else {
+        g.k = 2;
+        while (cols % g.k != 0 || cols / g.k > 256) ++g.k;
+        g.rpi = 1;
+        g.threads = cols / g.k;
+    }
+    int ppc = cdiv(HW, 256);
+    if (ppc < 32) ppc = 32;
+    ppc = cdiv(ppc, g.rpi) * g.rpi;
+    g.ppc = ppc;
+    g.nchunk = cdiv(HW, ppc);
+    return g;
+}
+
+int gn_nchunks(int HW, int C) { return gn_geom(HW, C).nchunk; }
+
+template <int K>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, int HW, int C, int rpi, int ppc,
+                                                       double* __restrict__ partial) {
+    extern __shared__ double sm[];  // [rpi][C][2]
+    const int cols = C >> 2;
+    const int colsk = cols / K;
+    const int tid = threadIdx.x;
+    const int row = tid / colsk;
+    const int col0 = tid - row * colsk;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int p0 = chunk * ppc;
+    const int p1 = min(HW, p0 + ppc);
+    double s[K][4], q[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[k][e] = q[k][e] = 0.0;
+    const float* base = x + (int64_t)n * HW * C;
+    for (int p = p0 + row; p < p1; p += rpi) {
+        const float4* rp = reinterpret_cast<const float4*>(base + (int64_t)p * C);
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float4 v = rp[col0 + k * colsk];
+            const double a = v.x, b = v.y, c = v.z, d = v.w;
+            s[k][0] += a; q[k][0] = fma(a, a, q[k][0]);
+            s[k][1] += b; q[k][1] = fma(b, b, q[k][1]);
+            s[k][2] += c; q[k][2] = fma(c, c, q[k][2]);
+            s[k][3] += d; q[k][3] = fma(d, d, q[k][3]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = (col0 + k * colsk) * 4 + e;
+            sm[((int64_t)row * C + c) * 2 + 0] = s[k][e];
+            sm[((int64_t)row * C + c) * 2 + 1] = q[k][e];
+        }
+    __syncthreads();
+    if (tid < GN_GROUPS) {
+        const int cpg = C / GN_GROUPS;
+        double ss = 0.0, qq = 0.0;
+        for (int r = 0; r < rpi; ++r)
+            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+                ss += sm[((int64_t)r * C + c) * 2 + 0];
+                qq += sm[((int64_t)r * C + c) * 2 + 1];
+            }
+        double* o = partial + (((int64_t)n * gridDim.x + chunk) * GN_GROUPS + tid) * 2;
+        o[0] = ss;
+        o[1] = qq;
+    }
+}
+
+void gn_stats(const float* x, int N, int HW, int C, double* partial, int nchunk, hipStream_t s) {
+    DSD_CHECK(C % GN_GROUPS == 0 && C % 4 == 0, "GroupNorm32: C=%d must be a multiple of 32", C);
+    const GnGeom g = gn_geom(HW, C);
+    DSD_CHECK(g.nchunk == nchunk, "gn_stats: chunk count mismatch");
+    const size_t lds = (size_t)g.rpi * C * 2 * sizeof(double);
+    DSD_CHECK(lds <= 64 * 1024, "gn_stats: C=%d too large", C);
+    const dim3 grid(g.nchunk, N), block(g.threads);
+    switch (g.k) {
+        case 1: hipLaunchKernelGGL(gn_stats_kernel<1>, grid, block, lds, s, x, HW, C, g.rpi, g.ppc, partial); break;
+        case 2: hipLaunchKernelGGL(gn_stats_kernel<2>, grid, block, lds, s, x, HW, C, g.rpi, g.ppc, partial); break;
+        case 3: hipLaunchKernelGGL(gn_stats_kernel<3>, grid, block, lds, s, x, HW, C, g.rpi, g.ppc, partial); break;
+        case 4: hipLaunchKernelGGL(gn_stats_kernel<4>, grid, block, lds, s, x, HW, C, g.rpi, g.ppc, partial); break;
+        default: fail("gn_stats: C=%d needs %d columns per thread (unsupported)", C, g.k);
+    }
+    check_launch("gn_stats");
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ partial, int nchunk, int HW, int C,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          const float* __restrict__ film, int film_stride,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double ps[8][GN_GROUPS][2];
+    __shared__ float mean_s[GN_GROUPS], rstd_s[GN_GROUPS];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int g = tid & 31, j = tid >> 5;
+    double ss = 0.0, qq = 0.0;
+    for (int ch = j; ch < nchunk; ch += 8) {
+        const double* o = partial + (((int64_t)n * nchunk + ch) * GN_GROUPS + g) * 2;
+        ss += o[0];
+        qq += o[1];
+    }
+    ps[j][g][0] = ss;
+    ps[j][g][1] = qq;
+    __syncthreads();
+    if (tid < GN_GROUPS) {
+        double a = 0.0, b = 0.0;
+        for (int r = 0; r < 8; ++r) {
+            a += ps[r][tid][0];
+            b += ps[r][tid][1];
+        }
+        const double cnt = (double)HW * (C / GN_GROUPS);
+        const double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[tid] = (float)mean;
+        rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const int cpg = C / GN_GROUPS;
+    for (int c = tid; c < C; c += 256) {
+        const int gg = c / cpg;
+        float sc = rstd_s[gg] * gamma[c];
+        float sh = beta[c] - mean_s[gg] * sc;
+        if (film) {  // (GN(x)) * (1 + fscale) + fshift, openaimodel.py:278-279
+            const float f = 1.f + film[(int64_t)n * film_stride + c];
+            sc *= f;
+            sh = sh * f + film[(int64_t)n * film_stride + C + c];
+        }
+        scale[(int64_t)n * C + c] = sc;
+        shift[(int64_t)n * C + c] = sh;
+    }
+}
+
+void gn_finalize(const double* partial, int nchunk, int N, int HW, int C, const float* gamma, const float* beta,
+                 float eps, const float* film, int film_stride, float* scale, float* shift, hipStream_t s) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, partial, nchunk, HW, C, gamma, beta, eps, film,
+                       film_stride, scale, shift);
+    check_launch("gn_finalize");
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + expf(-v)); }
+
+template <int ACT>
+__global__ __launch_bounds__(256) void affine_act_kernel(const float4* __restrict__ x, int64_t total4, int cols,
+                                                         int64_t per_sample4, const float4* __restrict__ scale,
+                                                         const float4* __restrict__ shift, float4* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int n = (int)(i / per_sample4);
+        const int c4 = (int)(i % cols);
+        const float4 v = x[i];
+        const float4 sc = scale[(int64_t)n * cols + c4];
+        const float4 sh = shift[(int64_t)n * cols + c4];
+        float4 o;
+        o.x = fmaf(v.x, sc.x, sh.x);
+        o.y = fmaf(v.y, sc.y, sh.y);
+        o.z = fmaf(v.z, sc.z, sh.z);
+        o.w = fmaf(v.w, sc.w, sh.w);
+        if (ACT == ACT_SILU) {
+            o.x = silu_f(o.x);
+            o.y = silu_f(o.y);
+            o.z = silu_f(o.z);
+            o.w = silu_f(o.w);
+        }
+        y[i] = o;
+    }
+}
+
+void affine_act(const float* x, int N, int HW, int C, const float* scale, const float* shift, int act, float* y,
+                hipStream_t s) {
+    const int cols = C / 4;
+    const int64_t per = (int64_t)HW * cols, total = per * N;
+    if (total == 0) return;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
+    if (act == ACT_SILU)
+        hipLaunchKernelGGL(affine_act_kernel<ACT_SILU>, dim3(blocks), dim3(256), 0, s, (const float4*)x, total, cols, per,
+                           (const float4*)scale, (const float4*)shift, (float4*)y);
+    else
+        hipLaunchKernelGGL(affine_act_kernel<ACT_NONE>, dim3(blocks), dim3(256), 0, s, (const float4*)x, total, cols, per,
+                           (const float4*)scale, (const float4*)shift, (float4*)y);
+    check_launch("affine_act");
+}
+
+// LayerNorm over the last dim: one wave per row, two-pass (mean, then centred variance) in fp32.
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, int64_t rows, int C,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps,
+                                                         float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = xr[c] - mean;
+        q = fmaf(d, d, q);
+    }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.f / sqrtf(q / C + eps);
+    for (int c = lane; c < C; c += 64) y[row * C + c] = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+}
+
+void layer_norm(const float* x, int64_t rows, int C, const float* gamma, const float* beta, float eps, float* y,
+                hipStream_t s) {
+    if (rows == 0) return;
+    hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, C, gamma, beta, eps, y);
+    check_launch("layer_norm");
+}
+
+}  // namespace dsd

@@ -1,0 +1,134 @@
+// sampler.hip — the per-step sampler update as ONE fused elementwise kernel (+ on-device Philox noise).
+//
+// Mode A  = guided-diffusion: p_mean_variance / p_sample / ddim_sample
+//           (Disc_diff/guided_diffusion/gaussian_diffusion.py:244-350, 422-465, 618-665)
+// Mode B  = LDM: DDPMModel.p_sample / p_mean_variance (trainers/trainer_ddpm.py:461-482, with
+//           ldm/models/diffusion/ddpm.py:284-311) and DDIMSampler.p_sample_ddim (ldm/models/diffusion/ddim.py:187-261).
+// The arithmetic is written in the reference's fp32 operation order; coefficient tables come from the host
+// (float64 there, rounded to fp32 once, like _extract_into_tensor(...).float() / the registered fp32 buffers).
+#include "kernels.h"
+#include "../../include/dsdiff.h"
+
+namespace dsd {
+
+// ---- Philox4x32-10 (Salmon et al. 2011): counter = (idx, step), key = seed
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                               uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+// element i of the normal stream for (seed, step): Box-Muller on the Philox block i/4... each block yields 4 normals
+__device__ __forceinline__ float philox_normal_at(int64_t i, uint64_t seed, uint64_t step) {
+    uint32_t r[4];
+    const uint64_t blk = (uint64_t)i >> 2;
+    philox4x32_10((uint32_t)blk, (uint32_t)(blk >> 32), (uint32_t)step, (uint32_t)(step >> 32), (uint32_t)seed,
+                  (uint32_t)(seed >> 32), r);
+    const int lane = (int)(i & 3);
+    const uint32_t a = r[lane & 2], b = r[(lane & 2) + 1];
+    const float u1 = ((float)a + 1.0f) * 2.3283064365386963e-10f;  // (0,1]
+    const float u2 = (float)b * 2.3283064365386963e-10f;           // [0,1)
+    const float rad = sqrtf(-2.0f * logf(u1));
+    const float ang = 6.283185307179586f * u2;
+    return (lane & 1) ? rad * sinf(ang) : rad * cosf(ang);
+}
+
+__global__ void philox_normal_kernel(float* __restrict__ y, int64_t n, uint64_t seed, uint64_t step) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        y[i] = philox_normal_at(i, seed, step);
+}
+
+void philox_normal(float* y, int64_t n, uint64_t seed, uint64_t step, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(philox_normal_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)), dim3(256), 0, s, y, n, seed, step);
+    check_launch("philox_normal");
+}
+
+__global__ __launch_bounds__(256) void sampler_update_kernel(StepCoef sc, const float* __restrict__ mo,
+                                                             float* __restrict__ x, const float* __restrict__ noise,
+                                                             uint64_t seed, uint64_t step, int B, int HW) {
+    const int64_t total = (int64_t)B * HW;
+    const int Cm = sc.learned_range ? 2 : 1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / HW;
+        const int64_t p = i - b * HW;
+        const float out = mo[(b * Cm) * HW + p];
+        const float xt = x[i];
+        const float z = noise ? noise[i] : philox_normal_at(i, seed, step);
+        const float* c = sc.c;
+        float x0, res;
+        if (sc.mode == DSD_MODE_B_DDIM) {
+            // ddim.py:222-260
+            float e_t;
+            if (sc.pred == DSD_PRED_V) {
+                e_t = c[0] * out + c[1] * xt;   // predict_eps_from_z_and_v ddpm.py:298-302
+                x0 = c[0] * xt - c[1] * out;    // predict_start_from_z_and_v ddpm.py:290-296
+            } else {
+                e_t = out;
+                x0 = (xt - c[7] * e_t) / sqrtf(c[4]);
+            }
+            if (sc.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+            const float dir = sqrtf(1.f - c[5] - c[6] * c[6]) * e_t;
+            res = sqrtf(c[5]) * x0 + dir + c[6] * z;
+        } else {
+            if (sc.pred == DSD_PRED_V)
+                x0 = c[0] * xt - c[1] * out;
+            else if (sc.pred == DSD_PRED_EPS)
+                x0 = c[2] * xt - c[3] * out;
+            else
+                x0 = out;
+            if (sc.clip) x0 = fminf(fmaxf(x0, -1.f), 1.f);
+            const float nz = sc.nonzero ? 1.f : 0.f;
+            if (sc.mode == DSD_MODE_A_DDIM) {
+                // gaussian_diffusion.py:646-664
+                const float eps = (c[2] * xt - x0) / c[3];
+                const float ab = c[4], abp = c[5];
+                const float sigma = sc.eta * sqrtf((1.f - abp) / (1.f - ab)) * sqrtf(1.f - ab / abp);
+                const float mean_pred = x0 * sqrtf(abp) + sqrtf(1.f - abp - sigma * sigma) * eps;
+                res = mean_pred + nz * sigma * z;
+            } else {
+                // DDPM: q_posterior mean + exp(0.5 logvar) z   (gaussian_diffusion.py:220-223,464; trainer_ddpm.py:467)
+                const float mean = c[4] * x0 + c[5] * xt;
+                float logvar = c[6];
+                if (sc.learned_range) {  // gaussian_diffusion.py:287-293
+                    const float v = mo[(b * Cm + 1) * HW + p];
+                    const float frac = (v + 1.f) / 2.f;
+                    logvar = frac * c[7] + (1.f - frac) * c[6];
+                }
+                res = mean + nz * expf(0.5f * logvar) * z;
+            }
+        }
+        x[i] = res;
+    }
+}
+
+void sampler_update(const StepCoef& sc, const float* model_out, float* x, const float* noise, uint64_t seed,
+                    uint64_t step, int B, int HW, hipStream_t s) {
+    const int64_t total = (int64_t)B * HW;
+    if (!total) return;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(sampler_update_kernel, dim3(blocks), dim3(256), 0, s, sc, model_out, x, noise, seed, step, B, HW);
+    check_launch("sampler_update");
+}
+
+__global__ void fill_t_kernel(float* t, int B, float v) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) t[i] = v;
+}
+void fill_t(float* t, int B, float v, hipStream_t s) {
+    hipLaunchKernelGGL(fill_t_kernel, dim3(cdiv(B, 64)), dim3(64), 0, s, t, B, v);
+    check_launch("fill_t");
+}
+
+}  // namespace dsd

@@ -1,0 +1,67 @@
+"""Kernel-level entry points (dsd_op_*) on torch CUDA tensors — used by tests and micro-benchmarks.
+
+Activations cross this boundary as NHWC; helpers convert from the reference's NCHW.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import lib, check, dptr, stream_ptr
+
+
+def to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def to_nchw(x: torch.Tensor) -> torch.Tensor:
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def conv2d(x_nhwc, w_oihw, bias, stride=1, upsample=False, emb=None, res=None):
+    N, H, W, Cin = x_nhwc.shape
+    Cout, _, ks, _ = w_oihw.shape
+    IH, IW = (H * 2, W * 2) if upsample else (H, W)
+    pad = ks // 2
+    OH, OW = (IH + 2 * pad - ks) // stride + 1, (IW + 2 * pad - ks) // stride + 1
+    y = torch.empty((N, OH, OW, Cout), device=x_nhwc.device, dtype=torch.float32)
+    check(lib().dsd_op_conv2d(dptr(x_nhwc), N, H, W, Cin, dptr(w_oihw.contiguous()), dptr(bias), Cout, ks, stride,
+                              int(upsample), dptr(emb), dptr(res), dptr(y), stream_ptr()))
+    return y
+
+
+def group_norm(x_nhwc, gamma, beta, eps=1e-5, silu=False):
+    N, H, W, Cc = x_nhwc.shape
+    y = torch.empty_like(x_nhwc)
+    check(lib().dsd_op_group_norm(dptr(x_nhwc), N, H * W, Cc, dptr(gamma), dptr(beta), eps, int(silu), dptr(y),
+                                  stream_ptr()))
+    return y
+
+
+def qkv_attention(qkv_ntc, heads, new_order=True):
+    N, T, C3 = qkv_ntc.shape
+    a = torch.empty((N, T, C3 // 3), device=qkv_ntc.device, dtype=torch.float32)
+    check(lib().dsd_op_qkv_attention(dptr(qkv_ntc), N, T, C3 // 3, heads, int(new_order), dptr(a), stream_ptr()))
+    return a
+
+
+def timestep_embedding(t, dim):
+    is_float = t.dtype.is_floating_point
+    t = t.float().contiguous() if is_float else t.long().contiguous()
+    y = torch.empty((t.shape[0], dim), device=t.device, dtype=torch.float32)
+    check(lib().dsd_op_timestep_embedding(C.c_void_p(t.data_ptr()), int(is_float), t.shape[0], dim, dptr(y), stream_ptr()))
+    return y
+
+
+def linear(x, w, bias=None, act_in=0):
+    N, K = x.shape
+    y = torch.empty((N, w.shape[0]), device=x.device, dtype=torch.float32)
+    check(lib().dsd_op_linear(dptr(x), N, K, dptr(w.contiguous()), dptr(bias), w.shape[0], act_in, dptr(y), stream_ptr()))
+    return y
+
+
+def philox_normal(n, seed, step, device="cuda"):
+    y = torch.empty((n,), device=device, dtype=torch.float32)
+    check(lib().dsd_op_philox_normal(dptr(y), n, seed, step, stream_ptr()))
+    return y

@@ -1,0 +1,171 @@
+/*
+ * dsdiff.h — C ABI of libdsdiff.so: the MI355X (gfx950) implementation of the conditional-DDPM
+ * sampling hot path of larrybb626/diffusion_models_dsdiff.
+ *
+ * Plain C: pointers, sizes, ints.  No torch types.  Every tensor pointer is a DEVICE pointer to
+ * contiguous fp32 unless stated otherwise; the caller owns inputs/outputs, the library owns the
+ * packed weights and the workspace.  Every entry point returns 0 on success, <0 on error
+ * (dsd_last_error() gives the message, thread-local).  All work is enqueued on the caller's
+ * hipStream_t (passed as void*; NULL = default stream) and is asynchronous w.r.t. the host.
+ * Calls on one handle are not re-entrant.
+ *
+ * Reference interfaces replaced (paths relative to the reference repo):
+ *   dsd_create / dsd_set_param     <- DSUnetModel.__init__           UNet_DS_Diff/model.py:172-611
+ *                                     + nn.Module.load_state_dict (names = reference state_dict keys)
+ *   dsd_forward                    <- DSUnetModel.forward            UNet_DS_Diff/model.py:629-756
+ *   dsd_sample                     <- GaussianDiffusion.p_sample_loop / ddim_sample_loop
+ *                                        Disc_diff/guided_diffusion/gaussian_diffusion.py:524-616,705-786
+ *                                     DDPMModel.p_sample_loop        trainers/trainer_ddpm.py:447-482
+ *                                     DDIMSampler.ddim_sampling      ldm/models/diffusion/ddim.py:128-261
+ *   dsd_block_*                    <- ResBlock / AttentionBlock / Upsample / Downsample
+ *                                        ldm/modules/diffusionmodules/openaimodel.py:93-164,167-284,426-473
+ *                                     FeatureDisentangle             UNet_DS_Diff/model.py:152-168
+ *                                     SE_Attention                   Disc_diff/guided_diffusion/unet.py:82-109
+ *                                     CrossAttention / BasicTransformerBlock / SpatialTransformer
+ *                                        ldm/modules/attention.py:145-194,302-331,366-428
+ *   dsd_op_*                       <- the stock torch ops those modules call (kernel-level tests)
+ */
+#ifndef DSDIFF_H
+#define DSDIFF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dsd_handle dsd_handle;
+
+#define DSD_MAX_LEVELS 8
+
+/* ctor kwargs of DSUnetModel that shape the graph (UNet_DS_Diff/model.py:172-202). */
+typedef struct dsd_config {
+    int32_t in_channels;        /* per-stream input channels (yaml: 1) */
+    int32_t model_channels;
+    int32_t out_channels;
+    int32_t n_levels;           /* len(channel_mult) */
+    int32_t channel_mult[DSD_MAX_LEVELS];
+    int32_t num_res_blocks[DSD_MAX_LEVELS];
+    int32_t n_attention_resolutions;
+    int32_t attention_resolutions[DSD_MAX_LEVELS];
+    int32_t num_heads;          /* -1 if unset */
+    int32_t num_head_channels;  /* -1 if unset */
+    int32_t num_heads_upsample; /* -1 if unset */
+    int32_t use_scale_shift_norm;
+    int32_t resblock_updown;
+    int32_t use_new_attention_order;
+    int32_t legacy;
+} dsd_config;
+
+/* Error text of the last failing call on this thread ("" if none). */
+const char* dsd_last_error(void);
+/* Library / device probe: returns 0 and fills name (<=255 chars) if a gfx950 device is usable. */
+int dsd_device_info(int device, char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
+
+/* ---- model handle ------------------------------------------------------------------------ */
+int dsd_create(const dsd_config* cfg, int device, dsd_handle** out);
+void dsd_destroy(dsd_handle* h);
+
+/* Parameter table (names/shapes identical to the reference state_dict, OIHW conv weights). */
+int dsd_param_count(dsd_handle* h);
+int dsd_param_info(dsd_handle* h, int idx, const char** name, int64_t shape[4], int* ndim);
+/* Upload one parameter. src is fp32 in the reference layout; src_is_device selects the copy kind.
+ * 3x3 conv weights are re-packed OIHW -> OHWI on device. */
+int dsd_set_param(dsd_handle* h, const char* name, const float* src, const int64_t* shape, int ndim,
+                  int src_is_device, void* stream);
+/* 0 if every parameter has been set, else -1 with the first missing name in dsd_last_error(). */
+int dsd_params_ready(dsd_handle* h);
+
+/* Build (or re-use) the launch plan + workspace for an input shape.  Allocation happens here,
+ * never inside dsd_forward/dsd_sample once the plan for that shape exists. */
+int dsd_plan(dsd_handle* h, int B, int C, int H, int W);
+int64_t dsd_workspace_bytes(dsd_handle* h);
+/* Number of kernel launches in the current plan's forward. */
+int dsd_plan_launches(dsd_handle* h);
+/* Algorithmic FLOPs (2*MAC of conv/linear/attention matmuls) of one forward of the current plan:
+ * executed = what the kernels really compute. */
+double dsd_plan_flops(dsd_handle* h);
+
+/* One denoising-network evaluation.  x: [B,C,H,W] (C in {2,4}, NCHW as the reference passes it),
+ * t: [B] int64 (t_is_float=0) or fp32 (t_is_float=1) on device, out: [B,out_channels,H,W].
+ * feats: NULL, or 14 device pointers to [B,half,H/2^(L-1),W/2^(L-1)] NCHW buffers in the order
+ * style[3], content[3], anatomy[2], lesion[2], n_style_content[4] (model.py:751-756). */
+int dsd_forward(dsd_handle* h, const float* x, const void* t, int t_is_float, int B, int C, int H, int W,
+                float* out, float* const* feats, void* stream);
+
+/* ---- sampling loop ----------------------------------------------------------------------- */
+enum { DSD_MODE_A_DDPM = 0, DSD_MODE_A_DDIM = 1, DSD_MODE_B_DDPM = 2, DSD_MODE_B_DDIM = 3 };
+enum { DSD_PRED_EPS = 0, DSD_PRED_X0 = 1, DSD_PRED_V = 2 };
+#define DSD_NCOEF 8
+/* Host-side schedule for `steps` loop iterations, iteration k = 0 is the FIRST executed (largest t).
+ * coef[k*DSD_NCOEF + j] fp32, meaning per mode (tables are produced in float64 on the host exactly as
+ * the reference does and rounded to fp32 once, gaussian_diffusion.py:1003 / ddpm.py:155-178):
+ *   A (guided-diffusion):  0 sqrt_acp  1 sqrt_1m_acp  2 sqrt_recip_acp  3 sqrt_recipm1_acp
+ *                          4 post_coef1  5 post_coef2  6 log_var(fixed) or min_log(learned range)  7 max_log
+ *        A_DDIM re-uses 0-3 and:  4 alpha_bar  5 alpha_bar_prev
+ *   B_DDPM (ldm):          0 sqrt_acp 1 sqrt_1m_acp 2 sqrt_recip_acp 3 sqrt_recipm1_acp 4 coef1 5 coef2 6 post_log_var
+ *   B_DDIM (ldm):          0 sqrt_acp 1 sqrt_1m_acp 4 a_t 5 a_prev 6 sigma_t 7 sqrt_1m_at
+ * t_model[k]: the timestep value handed to the network at iteration k (timestep_map[t], optionally
+ * rescaled, respace.py:123-128); nonzero[k]: 0 only where the reference masks the noise (t == 0). */
+typedef struct dsd_schedule {
+    int32_t steps;
+    int32_t mode;          /* DSD_MODE_* */
+    int32_t pred;          /* DSD_PRED_* */
+    int32_t learned_range; /* model emits 2*C channels, LEARNED_RANGE variance (gaussian_diffusion.py:280-294) */
+    int32_t clip_denoised;
+    float eta;             /* DDIM eta (A_DDIM computes sigma on device from alpha_bar, alpha_bar_prev) */
+    const float* coef;     /* host, steps*DSD_NCOEF */
+    const float* t_model;  /* host, steps */
+    const int32_t* nonzero;/* host, steps */
+} dsd_schedule;
+
+/* Runs the whole loop on the device.  x: [B,1,H,W] in = x_T, out = x_0 (in place).  cond: [B,Cc,H,W]
+ * (Cc in {1,3}) concatenated after x every step (DiffusionWrapper 'concat', ddpm.py:1331-1333).
+ * noise: NULL -> on-device Philox4x32-10 N(0,1) from philox_seed; else [steps,B,1,H,W] pre-drawn
+ * normals, noise[k] used at iteration k (parity mode).  first_step/n_steps select a sub-range of
+ * iterations (n_steps<=0 = all) so a caller can time or checkpoint part of the chain. */
+int dsd_sample(dsd_handle* h, const dsd_schedule* sched, const float* cond, int Cc, float* x, const float* noise,
+               uint64_t philox_seed, int B, int H, int W, int first_step, int n_steps, void* stream);
+/* The fused sampler update alone (one step), for kernel-level tests: model_out [B,Cm,H,W]. */
+int dsd_op_sampler_update(const dsd_schedule* sched, int k, const float* model_out, float* x, const float* noise,
+                          uint64_t philox_seed, int B, int H, int W, void* stream);
+
+/* ---- single blocks (own parameter namespace, names relative to the block) ----------------- */
+enum { DSD_BLOCK_RES = 0, DSD_BLOCK_ATTN = 1, DSD_BLOCK_UPSAMPLE = 2, DSD_BLOCK_DOWNSAMPLE = 3,
+       DSD_BLOCK_DISENTANGLE = 4, DSD_BLOCK_SE = 5, DSD_BLOCK_CROSSATTN = 6, DSD_BLOCK_FF_GEGLU = 7,
+       DSD_BLOCK_BASIC_TRANSFORMER = 8, DSD_BLOCK_SPATIAL_TRANSFORMER = 9 };
+/* iargs by kind:
+ *   RES: cin, cout, emb_ch, use_scale_shift_norm, up, down      ATTN: ch, heads, new_order
+ *   UPSAMPLE/DOWNSAMPLE: ch     DISENTANGLE: ch, half_ch       SE: ch, reduction
+ *   CROSSATTN: query_dim, context_dim, heads, dim_head          FF_GEGLU: dim, mult
+ *   BASIC_TRANSFORMER: dim, heads, dim_head, context_dim
+ *   SPATIAL_TRANSFORMER: in_ch, heads, dim_head, depth, context_dim, use_linear */
+int dsd_block_create(int kind, const int32_t* iargs, int n_iargs, int device, dsd_handle** out);
+/* x: NCHW [B,C,H,W] (token blocks: [B,N,C] passed as H=N, W=1 "NHWC"), aux: emb [B,emb_ch] for RES,
+ * context [B,Nc,Cc] for cross-attention kinds (aux2/aux_len2 = second context for depth-2 spatial
+ * transformer), else NULL.  out sized as the block's output. */
+int dsd_block_forward(dsd_handle* h, const float* x, int B, int C, int H, int W, const float* aux, int aux_len,
+                      const float* aux2, int aux_len2, float* out, void* stream);
+
+/* ---- kernel-level ops (NHWC activations; used by tests and micro-benchmarks) -------------- */
+/* y[N,OH,OW,Cout] = conv(x[N,H,W,Cin], w OIHW ks x ks, pad ks/2, stride) + bias (+ emb[N,Cout]) (+ res) ;
+ * upsample=1 folds a nearest x2 in front of the conv (Upsample, openaimodel.py:111-121). */
+int dsd_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
+                  int ks, int stride, int upsample, const float* emb, const float* res, float* y, void* stream);
+/* GroupNorm(32, C, eps) [+ SiLU] on x[N,HW,C]. */
+int dsd_op_group_norm(const float* x, int N, int HW, int C, const float* gamma, const float* beta, float eps,
+                      int silu, float* y, void* stream);
+/* QKVAttention / QKVAttentionLegacy (openaimodel.py:496-555) on qkv[N,T,3C] -> a[N,T,C]. */
+int dsd_op_qkv_attention(const float* qkv, int N, int T, int C, int heads, int new_order, float* a, void* stream);
+/* timestep_embedding (util.py:161-181): t[N] (int64 or fp32) -> [N,dim]. */
+int dsd_op_timestep_embedding(const void* t, int t_is_float, int N, int dim, float* y, void* stream);
+/* y[N,O] = act_in(x[N,K]) @ w[O,K]^T + bias ; act_in: 0 none, 1 SiLU. */
+int dsd_op_linear(const float* x, int N, int K, const float* w, const float* bias, int O, int act_in, float* y,
+                  void* stream);
+/* Philox4x32-10 + Box-Muller stream used by dsd_sample when noise == NULL: fills n normals. */
+int dsd_op_philox_normal(float* y, int64_t n, uint64_t seed, uint64_t step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSDIFF_H */
