@@ -1,0 +1,251 @@
+"""GaussianDiffusion — drop-in for Disc_diff/guided_diffusion/gaussian_diffusion.py (sampling side).
+
+Same constructor, enums and sampling entry points as the reference (``p_sample_loop`` :524-567,
+``ddim_sample_loop`` :705-737, ``p_sample`` :422-465, ``ddim_sample`` :618-665 and their
+``*_progressive`` generators).  The float64 schedule tables are built on the host exactly as
+:141-178 does; the loop itself (network + fused update) runs on the MI355X through dsd_sample.
+Training losses are out of scope.
+"""
+from __future__ import annotations
+
+import enum
+import math
+
+import numpy as np
+import torch as th
+
+from ... import _lib
+from ..._sched import Schedule, find_unet, run_device_loop, sampler_update, _seed_from_torch
+
+
+def get_named_beta_schedule(schedule_name, num_diffusion_timesteps):
+    """gaussian_diffusion.py:31-54."""
+    if schedule_name == "linear":
+        scale = 1000 / num_diffusion_timesteps
+        return np.linspace(scale * 0.0001, scale * 0.02, num_diffusion_timesteps, dtype=np.float64)
+    if schedule_name == "cosine":
+        return betas_for_alpha_bar(num_diffusion_timesteps,
+                                   lambda t: math.cos((t + 0.008) / 1.008 * math.pi / 2) ** 2)
+    raise NotImplementedError(f"unknown beta schedule: {schedule_name}")
+
+
+def betas_for_alpha_bar(num_diffusion_timesteps, alpha_bar, max_beta=0.999):
+    """gaussian_diffusion.py:57-73."""
+    n = num_diffusion_timesteps
+    return np.array([min(1 - alpha_bar((i + 1) / n) / alpha_bar(i / n), max_beta) for i in range(n)])
+
+
+class ModelMeanType(enum.Enum):
+    PREVIOUS_X = enum.auto()
+    START_X = enum.auto()
+    EPSILON = enum.auto()
+
+
+class ModelVarType(enum.Enum):
+    LEARNED = enum.auto()
+    FIXED_SMALL = enum.auto()
+    FIXED_LARGE = enum.auto()
+    LEARNED_RANGE = enum.auto()
+
+
+class LossType(enum.Enum):
+    MSE = enum.auto()
+    RESCALED_MSE = enum.auto()
+    KL = enum.auto()
+    RESCALED_KL = enum.auto()
+
+    def is_vb(self):
+        return self == LossType.KL or self == LossType.RESCALED_KL
+
+
+class GaussianDiffusion:
+    def __init__(self, *, betas, model_mean_type, model_var_type, loss_type, rescale_timesteps=False,
+                 parameterization="eps"):
+        self.model_mean_type = model_mean_type
+        self.model_var_type = model_var_type
+        self.loss_type = loss_type
+        self.rescale_timesteps = rescale_timesteps
+        self.parameterization = parameterization
+        betas = np.array(betas, dtype=np.float64)
+        self.betas = betas
+        assert len(betas.shape) == 1, "betas must be 1-D"
+        assert (betas > 0).all() and (betas <= 1).all()
+        self.num_timesteps = int(betas.shape[0])
+        one_minus = 1.0 - betas
+        self.alphas_cumprod = np.cumprod(one_minus, axis=0)
+        self.alphas_cumprod_prev = np.append(1.0, self.alphas_cumprod[:-1])
+        self.alphas_cumprod_next = np.append(self.alphas_cumprod[1:], 0.0)
+        self.sqrt_alphas_cumprod = np.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = np.sqrt(1.0 - self.alphas_cumprod)
+        self.log_one_minus_alphas_cumprod = np.log(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = np.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = np.log(np.append(self.posterior_variance[1], self.posterior_variance[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * np.sqrt(one_minus) / (1.0 - self.alphas_cumprod)
+
+    # ------------------------------------------------------------------ host -> device schedule
+    def _model_timestep_values(self) -> np.ndarray:
+        """Value handed to the network for loop index i (``_scale_timesteps`` :381-384; overridden by SpacedDiffusion)."""
+        t = np.arange(self.num_timesteps, dtype=np.float32)
+        if self.rescale_timesteps:
+            t = t * np.float32(1000.0 / self.num_timesteps)
+        return t
+
+    def _pred_code(self) -> int:
+        if self.parameterization == "v":
+            return _lib.PRED_V
+        if self.model_mean_type == ModelMeanType.EPSILON:
+            return _lib.PRED_EPS
+        if self.model_mean_type == ModelMeanType.START_X:
+            return _lib.PRED_X0
+        raise NotImplementedError("ModelMeanType.PREVIOUS_X is not used by any shipped config")
+
+    def _schedule(self, ddim: bool, eta: float, clip_denoised: bool) -> Schedule:
+        T = self.num_timesteps
+        idx = np.arange(T - 1, -1, -1)                          # loop order: i = T-1 .. 0  (:595,:764)
+        f32 = lambda a: np.asarray(a, dtype=np.float64)[idx].astype(np.float32)   # arr[t].float()  (:1003)
+        coef = np.zeros((T, _lib.DSD_NCOEF), dtype=np.float32)
+        coef[:, 0] = f32(self.sqrt_alphas_cumprod)
+        coef[:, 1] = f32(self.sqrt_one_minus_alphas_cumprod)
+        coef[:, 2] = f32(self.sqrt_recip_alphas_cumprod)
+        coef[:, 3] = f32(self.sqrt_recipm1_alphas_cumprod)
+        learned = self.model_var_type == ModelVarType.LEARNED_RANGE
+        if self.model_var_type == ModelVarType.LEARNED:
+            raise NotImplementedError("ModelVarType.LEARNED is not used by any shipped config")
+        if ddim:
+            coef[:, 4] = f32(self.alphas_cumprod)
+            coef[:, 5] = f32(self.alphas_cumprod_prev)
+        else:
+            coef[:, 4] = f32(self.posterior_mean_coef1)
+            coef[:, 5] = f32(self.posterior_mean_coef2)
+            if learned:                                          # :287-290
+                coef[:, 6] = f32(self.posterior_log_variance_clipped)
+                coef[:, 7] = f32(np.log(self.betas))
+            elif self.model_var_type == ModelVarType.FIXED_LARGE:   # :299-302
+                coef[:, 6] = f32(np.log(np.append(self.posterior_variance[1], self.betas[1:])))
+            else:                                                # FIXED_SMALL :303-306
+                coef[:, 6] = f32(self.posterior_log_variance_clipped)
+        t_model = self._model_timestep_values()[idx]
+        nonzero = (idx != 0).astype(np.int32)                    # :457-459
+        mode = _lib.MODE_A_DDIM if ddim else _lib.MODE_A_DDPM
+        return Schedule(mode, self._pred_code(), coef, t_model, nonzero, learned_range=learned,
+                        clip_denoised=clip_denoised, eta=eta)
+
+    # ------------------------------------------------------------------ loops
+    def _loop(self, ddim, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
+              eta=0.0, step_noise=None, seed=None):
+        if denoised_fn is not None or cond_fn is not None:
+            raise NotImplementedError("denoised_fn / cond_fn hooks are not supported by the device loop")
+        assert isinstance(shape, (tuple, list))
+        model_kwargs = model_kwargs or {}
+        sched = self._schedule(ddim, eta, clip_denoised)
+        unet = find_unet(model)
+        if device is None:
+            device = next(model.parameters()).device if hasattr(model, "parameters") else th.device("cuda")
+            if th.device(device).type != "cuda":
+                device = th.device("cuda")
+        img = noise if noise is not None else th.randn(*shape, device=device)      # :591-594
+        img = img.to(device)
+        c_concat = model_kwargs.get("c_concat")
+        if unet is not None and c_concat is not None:
+            cond = th.cat([c.to(device) for c in c_concat], 1)
+            return run_device_loop(unet, sched, img, cond, step_noise=step_noise, seed=seed)
+        # generic callable (closure / foreign module): python loop, fused HIP update per step
+        seed = _seed_from_torch() if seed is None else seed
+        x = img.float().contiguous().clone()
+        B = x.shape[0]
+        tvals = th.from_numpy(sched.t_model)
+        for k in range(sched.steps):
+            tv = tvals[k]
+            is_int = (not self.rescale_timesteps) and float(tv) == int(tv)
+            t = th.full((B,), int(tv) if is_int else float(tv), device=device,
+                        dtype=th.long if is_int else th.float32)
+            out = model(x, t, **model_kwargs)
+            if isinstance(out, tuple):
+                out = out[0]
+            sampler_update(sched, k, out, x, None if step_noise is None else step_noise[k].to(device), seed)
+        return x
+
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                      model_kwargs=None, device=None, progress=False, step_noise=None, seed=None):
+        """:524-567.  ``step_noise`` ([T,B,1,H,W]) / ``seed`` are extensions: injected normals (parity runs) or
+        the Philox seed; by default the per-step noise is on-device Philox seeded from torch's generator."""
+        return self._loop(False, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
+                          progress, 0.0, step_noise, seed)
+
+    def ddim_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                         model_kwargs=None, device=None, progress=False, eta=0.0, step_noise=None, seed=None):
+        """:705-737."""
+        return self._loop(True, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
+                          progress, eta, step_noise, seed)
+
+    def _progressive(self, ddim, model, shape, noise, clip_denoised, model_kwargs, device, eta):
+        model_kwargs = model_kwargs or {}
+        sched = self._schedule(ddim, eta, clip_denoised)
+        if device is None:
+            device = th.device("cuda")
+        img = (noise if noise is not None else th.randn(*shape, device=device)).to(device).float().contiguous().clone()
+        seed = _seed_from_torch()
+        B = img.shape[0]
+        for k in range(sched.steps):
+            i = self.num_timesteps - 1 - k
+            t = th.tensor([i] * B, device=device)
+            out = self._call_model(model, img, t, model_kwargs)
+            x0 = sampler_update(sched, k, out, img, None, seed, want_x0=True)
+            yield {"sample": img.clone(), "pred_xstart": x0}
+
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
+                                  model_kwargs=None, device=None, progress=False):
+        """:569-616 (yields {"sample","pred_xstart"} per step)."""
+        assert denoised_fn is None and cond_fn is None
+        yield from self._progressive(False, model, shape, noise, clip_denoised, model_kwargs, device, 0.0)
+
+    def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                     cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0):
+        """:739-786."""
+        assert denoised_fn is None and cond_fn is None
+        yield from self._progressive(True, model, shape, noise, clip_denoised, model_kwargs, device, eta)
+
+    # ------------------------------------------------------------------ single steps
+    def _scale_timesteps(self, t):
+        if self.rescale_timesteps:
+            return t.float() * (1000.0 / self.num_timesteps)
+        return t
+
+    def _call_model(self, model, x, t, model_kwargs):
+        """p_mean_variance's network call (:266-278): loop index -> network timestep, tuple -> tensor."""
+        tv = th.from_numpy(self._model_timestep_values()).to(x.device)[t]
+        if not self.rescale_timesteps:
+            tv = tv.long()
+        out = model(x, tv, **model_kwargs)
+        return out[0] if isinstance(out, tuple) else out
+
+    def _single(self, ddim, model, x, t, clip_denoised, model_kwargs, eta):
+        model_kwargs = model_kwargs or {}
+        i = int(t[0])
+        assert bool((t == i).all()), "all samples of a batch share the timestep in every reference loop"
+        sched = self._schedule(ddim, eta, clip_denoised)
+        out = self._call_model(model, x, t, model_kwargs)
+        xn = x.float().contiguous().clone()
+        x0 = sampler_update(sched, self.num_timesteps - 1 - i, out, xn, None, _seed_from_torch(), want_x0=True)
+        return {"sample": xn, "pred_xstart": x0}
+
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None):
+        """:422-465."""
+        assert denoised_fn is None and cond_fn is None
+        return self._single(False, model, x, t, clip_denoised, model_kwargs, 0.0)
+
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0):
+        """:618-665."""
+        assert denoised_fn is None and cond_fn is None
+        return self._single(True, model, x, t, clip_denoised, model_kwargs, eta)
+
+
+def _extract_into_tensor(arr, timesteps, broadcast_shape):
+    """:994-1006."""
+    res = th.from_numpy(arr).to(device=timesteps.device)[timesteps].float()
+    while len(res.shape) < len(broadcast_shape):
+        res = res[..., None]
+    return res.expand(broadcast_shape)

@@ -1,0 +1,244 @@
+"""DSUnetModel — drop-in for the reference's UNet_DS_Diff/model.py:171-756, executed by libdsdiff.so.
+
+Same constructor keyword arguments (UNet_DS_Diff/model.py:172-202), same ``state_dict`` names and
+shapes (OIHW conv weights), same ``forward(x, timesteps, context=None, y=None)`` returning
+``(out, dict)`` (model.py:629-663,751-756).  The nn.Module only *holds* the parameters (so Lightning /
+``load_state_dict`` / ``.to()`` behave as usual); every FLOP runs in hand-written gfx950 kernels behind
+the C ABI (include/dsdiff.h).  No CPU path: construction fails if the library or the GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .._lib import DsdConfig, check, dptr, lib, stream_ptr
+
+FEAT_KEYS = (("style", 3), ("content", 3), ("anatomy", 2), ("lesion", 2), ("n_style_content", 4))
+
+
+class _Holder(nn.Module):
+    """Nameless container so parameter paths match the reference module tree."""
+
+
+def _is_zero_init(name: str) -> bool:
+    """zero_module() sites of the reference: ResBlock.out_layers[-1] (openaimodel.py:233-235),
+    AttentionBlock.proj_out (:460), DSUnetModel.out[-1] (model.py:514)."""
+    return (".out_layers.3." in name or name.startswith("out_layers.3.") or ".proj_out." in name
+            or name.startswith("proj_out.") or name.startswith("out.2."))
+
+
+class NativeModule(nn.Module):
+    """An nn.Module whose parameters mirror a libdsdiff handle's parameter table."""
+
+    def __init__(self):
+        super().__init__()
+        self._h = C.c_void_p()
+        self._uploaded: Dict[str, tuple] = {}
+        self._device_index = 0
+
+    # ---- parameter tree from the C-side table (names identical to the reference state_dict)
+    def _build_params(self):
+        L = lib()
+        n = L.dsd_param_count(self._h)
+        name, shape, ndim = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+        fan_in: Dict[str, int] = {}
+        for i in range(n):
+            check(L.dsd_param_info(self._h, i, C.byref(name), shape, C.byref(ndim)))
+            nm = name.value.decode()
+            shp = tuple(int(shape[k]) for k in range(ndim.value))
+            p = nn.Parameter(torch.empty(shp, dtype=torch.float32), requires_grad=False)
+            base = nm.rsplit(".", 1)[0]
+            with torch.no_grad():
+                if _is_zero_init(nm):
+                    p.zero_()
+                elif len(shp) >= 2:                      # nn.Conv*/nn.Linear default: kaiming_uniform(a=sqrt(5))
+                    fi = int(torch.tensor(shp[1:]).prod())
+                    fan_in[base] = fi
+                    p.uniform_(-1.0 / math.sqrt(fi), 1.0 / math.sqrt(fi))
+                elif nm.endswith(".bias") and base in fan_in:
+                    p.uniform_(-1.0 / math.sqrt(fan_in[base]), 1.0 / math.sqrt(fan_in[base]))
+                elif nm.endswith(".weight"):            # GroupNorm / LayerNorm
+                    p.fill_(1.0)
+                else:
+                    p.zero_()
+            mod = self
+            parts = nm.split(".")
+            for part in parts[:-1]:
+                if part not in mod._modules:
+                    mod.add_module(part, _Holder())
+                mod = mod._modules[part]
+            mod.register_parameter(parts[-1], p)
+
+    def sync_params(self, force: bool = False):
+        """Upload parameters that changed since the last upload (load_state_dict, .to(), in-place edits)."""
+        L = lib()
+        for nm, p in self.named_parameters():
+            key = (p.data_ptr(), p._version, p.device.type)
+            if not force and self._uploaded.get(nm) == key:
+                continue
+            t = p.detach()
+            if t.dtype != torch.float32:
+                t = t.float()
+            t = t.contiguous()
+            shp = (C.c_int64 * max(1, t.dim()))(*t.shape)
+            check(L.dsd_set_param(self._h, nm.encode(), C.c_void_p(t.data_ptr()), shp, t.dim(), int(t.is_cuda),
+                                  stream_ptr() if t.is_cuda else None))
+            self._uploaded[nm] = key
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().dsd_destroy(self._h)
+                self._h = C.c_void_p()
+        except Exception:
+            pass
+
+
+class DSUnetModel(NativeModule):
+    def __init__(self,
+                 image_size=None,
+                 in_channels=1,
+                 model_channels=320,
+                 out_channels=1,
+                 num_res_blocks=2,
+                 attention_resolutions=(),
+                 dropout=0,
+                 channel_mult=(1, 2, 4, 8),
+                 conv_resample=True,
+                 dims=2,
+                 num_classes=None,
+                 use_checkpoint=False,
+                 use_fp16=False,
+                 use_bf16=False,
+                 num_heads=-1,
+                 num_head_channels=-1,
+                 num_heads_upsample=-1,
+                 use_scale_shift_norm=False,
+                 resblock_updown=False,
+                 use_new_attention_order=False,
+                 use_spatial_transformer=False,
+                 transformer_depth=1,
+                 context_dim=None,
+                 n_embed=None,
+                 legacy=True,
+                 disable_self_attentions=None,
+                 num_attention_blocks=None,
+                 disable_middle_self_attn=False,
+                 use_linear_in_transformer=False,
+                 adm_in_channels=None,
+                 device_index: int = 0):
+        super().__init__()
+        # the same argument checks as the reference ctor (model.py:204-219,225-231)
+        if use_spatial_transformer:
+            assert context_dim is not None, "context_dim must be provided for spatial transformer"
+            raise NotImplementedError("use_spatial_transformer=True raises NameError in the reference too "
+                                      "(UNet_DS_Diff/model.py:20 imports only SpatialTransformer_fft)")
+        if context_dim is not None:
+            assert use_spatial_transformer, "Fool!! You forgot to use the spatial transformer for your cross-attention conditioning..."
+        if num_heads == -1:
+            assert num_head_channels != -1, "Either num_heads or num_head_channels has to be set"
+        if num_head_channels == -1:
+            assert num_heads != -1, "Either num_heads or num_head_channels has to be set"
+        if num_classes is not None or n_embed is not None:
+            raise NotImplementedError("class-conditional / codebook heads are not on the sampling hot path")
+        if dims != 2 or not conv_resample or dropout != 0 or use_fp16 or use_bf16:
+            raise NotImplementedError("hot path is dims=2, conv_resample=True, dropout=0, fp32 (SURVEY.md 8)")
+        if disable_self_attentions is not None or num_attention_blocks is not None:
+            raise NotImplementedError("disable_self_attentions / num_attention_blocks are unused by every shipped yaml")
+        channel_mult = list(channel_mult)
+        if isinstance(num_res_blocks, int):
+            nrb = len(channel_mult) * [num_res_blocks]
+        else:
+            nrb = list(num_res_blocks)
+            if len(nrb) != len(channel_mult):
+                raise ValueError("provide num_res_blocks either as an int (globally constant) or "
+                                 "as a list/tuple (per-level) with the same length as channel_mult")
+        self.image_size = image_size
+        self.in_channels = in_channels
+        self.model_channels = model_channels
+        self.out_channels = out_channels
+        self.num_res_blocks = nrb
+        self.attention_resolutions = list(attention_resolutions)
+        self.channel_mult = channel_mult
+        self.num_classes = None
+        self.dtype = torch.float32
+        self._device_index = device_index
+
+        _lib.require_gpu(device_index)
+        cfg = DsdConfig()
+        cfg.in_channels, cfg.model_channels, cfg.out_channels = in_channels, model_channels, out_channels
+        cfg.n_levels = len(channel_mult)
+        for i, (m, r) in enumerate(zip(channel_mult, nrb)):
+            cfg.channel_mult[i], cfg.num_res_blocks[i] = int(m), int(r)
+        cfg.n_attention_resolutions = len(self.attention_resolutions)
+        for i, a in enumerate(self.attention_resolutions):
+            cfg.attention_resolutions[i] = int(a)
+        cfg.num_heads, cfg.num_head_channels, cfg.num_heads_upsample = num_heads, num_head_channels, num_heads_upsample
+        cfg.use_scale_shift_norm = int(bool(use_scale_shift_norm))
+        cfg.resblock_updown = int(bool(resblock_updown))
+        cfg.use_new_attention_order = int(bool(use_new_attention_order))
+        cfg.legacy = int(bool(legacy))
+        self._cfg = cfg
+        check(lib().dsd_create(C.byref(cfg), device_index, C.byref(self._h)))
+        self._build_params()
+        # timestep_embedding's frequency table exactly as the reference evaluates it (util.py:172-174, torch CPU fp32 exp)
+        half = model_channels // 2
+        freqs = torch.exp(-math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32) / half).contiguous()
+        check(lib().dsd_set_timestep_freqs(self._h, C.c_void_p(freqs.data_ptr()), half))
+        self._half = int(int(channel_mult[0] * model_channels) * channel_mult[-1] / 2)
+
+    # ---- reference API ---------------------------------------------------------------------------
+    def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
+        """model.py:629-756.  x: [B,C,H,W] fp32 CUDA with C in {2,4}; timesteps: [B] int64 or float."""
+        assert (y is not None) == (self.num_classes is not None), \
+            "must specify y if and only if the model is class-conditional"
+        out, feats = self._run(x, timesteps, want_feats=True)
+        return out, feats
+
+    @torch.no_grad()
+    def _run(self, x, timesteps, want_feats: bool):
+        if not x.is_cuda:
+            raise _lib.DsdError("DSUnetModel runs on the MI355X only: input tensor is on the CPU (no CPU fallback)")
+        self.sync_params()
+        x = x.float().contiguous()
+        B, Cc, H, W = x.shape
+        t = timesteps.to(x.device)
+        t_is_float = t.dtype.is_floating_point
+        t = (t.float() if t_is_float else t.long()).contiguous()
+        assert t.shape == (B,)
+        out = torch.empty((B, self.out_channels, H, W), device=x.device, dtype=torch.float32)
+        feats_t: List[torch.Tensor] = []
+        fptr = None
+        if want_feats:
+            ds = 2 ** (len(self.channel_mult) - 1)
+            feats_t = [torch.empty((B, self._half, H // ds, W // ds), device=x.device, dtype=torch.float32)
+                       for _ in range(14)]
+            fptr = (C.c_void_p * 14)(*[f.data_ptr() for f in feats_t])
+        check(lib().dsd_forward(self._h, dptr(x), C.c_void_p(t.data_ptr()), int(t_is_float), B, Cc, H, W, dptr(out),
+                                fptr, stream_ptr()))
+        feats = {}
+        if want_feats:
+            i = 0
+            for k, n in FEAT_KEYS:
+                feats[k] = feats_t[i:i + n]
+                i += n
+        return out, feats
+
+    # ---- introspection used by bench.py / tests
+    def plan_info(self):
+        L = lib()
+        return {"workspace_bytes": int(L.dsd_workspace_bytes(self._h)), "launches": int(L.dsd_plan_launches(self._h)),
+                "flops": float(L.dsd_plan_flops(self._h))}
+
+    def convert_to_fp16(self):
+        raise NotImplementedError("the hot path is fp32 end-to-end (SURVEY.md 9, quirk 8)")
+
+    def convert_to_fp32(self):
+        return None

@@ -23,7 +23,7 @@ PRED_EPS, PRED_X0, PRED_V = 0, 1, 2
 # every symbol include/dsdiff.h declares (tests/test_abi.py checks the header against this list)
 EXPORTS = [
     "dsd_last_error", "dsd_device_info", "dsd_create", "dsd_destroy", "dsd_param_count", "dsd_param_info",
-    "dsd_set_param", "dsd_params_ready", "dsd_plan", "dsd_workspace_bytes", "dsd_plan_launches", "dsd_plan_flops",
+    "dsd_set_param", "dsd_set_timestep_freqs", "dsd_params_ready", "dsd_plan", "dsd_workspace_bytes", "dsd_plan_launches", "dsd_plan_flops",
     "dsd_forward", "dsd_sample", "dsd_op_sampler_update", "dsd_block_create", "dsd_block_forward", "dsd_op_conv2d",
     "dsd_op_group_norm", "dsd_op_qkv_attention", "dsd_op_timestep_embedding", "dsd_op_linear", "dsd_op_philox_normal",
 ]
@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
     L.dsd_param_count.argtypes = [vp]
     L.dsd_param_info.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     L.dsd_set_param.argtypes = [vp, C.c_char_p, f32p, C.POINTER(C.c_int64), i32, i32, vp]
+    L.dsd_set_timestep_freqs.argtypes = [vp, f32p, i32]
     L.dsd_params_ready.argtypes = [vp]
     L.dsd_plan.argtypes = [vp, i32, i32, i32, i32]
     L.dsd_workspace_bytes.argtypes = [vp]
@@ -91,7 +92,7 @@ def lib() -> C.CDLL:
     L.dsd_plan_flops.restype = C.c_double
     L.dsd_forward.argtypes = [vp, f32p, vp, i32, i32, i32, i32, i32, f32p, C.POINTER(vp), vp]
     L.dsd_sample.argtypes = [vp, C.POINTER(DsdSchedule), f32p, i32, f32p, f32p, C.c_uint64, i32, i32, i32, i32, i32, vp]
-    L.dsd_op_sampler_update.argtypes = [C.POINTER(DsdSchedule), i32, f32p, f32p, f32p, C.c_uint64, i32, i32, i32, vp]
+    L.dsd_op_sampler_update.argtypes = [C.POINTER(DsdSchedule), i32, f32p, f32p, f32p, C.c_uint64, i32, i32, i32, f32p, vp]
     L.dsd_block_create.argtypes = [i32, C.POINTER(C.c_int32), i32, i32, C.POINTER(vp)]
     L.dsd_block_forward.argtypes = [vp, f32p, i32, i32, i32, i32, f32p, i32, f32p, i32, f32p, vp]
     L.dsd_op_conv2d.argtypes = [f32p, i32, i32, i32, i32, f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, vp]

@@ -41,14 +41,16 @@ struct Tmp {
     explicit Tmp(size_t bytes) { DSD_HIP(hipMalloc(&p, bytes ? bytes : 256)); }
     ~Tmp() {
         if (p) {
-            hipDeviceSynchronize();
-            hipFree(p);
+            (void)hipDeviceSynchronize();
+            (void)hipFree(p);
         }
     }
     template <class T> T* as() { return reinterpret_cast<T*>(p); }
 };
 
-void set_device(int device) { DSD_HIP(hipSetDevice(device)); }
+void set_device(int device) {
+    if (device >= 0) DSD_HIP(hipSetDevice(device));
+}
 
 void bind_planes(dsd_handle* h, const float* x, int C, int H, int W, hipStream_t s) {
     const int64_t hw = (int64_t)H * W;
@@ -133,8 +135,10 @@ int dsd_block_create(int kind, const int32_t* iargs, int n_iargs, int device, ds
 
 void dsd_destroy(dsd_handle* h) {
     if (!h) return;
-    hipSetDevice(h->device);
-    hipDeviceSynchronize();
+    if (h->device >= 0) {
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();
+    }
     net_free(h);
     delete h;
 }
@@ -158,6 +162,16 @@ int dsd_set_param(dsd_handle* h, const char* name, const float* src, const int64
     DSD_CHECK(h && name && src && shape, "null argument");
     set_device(h->device);
     net_set_param(h, name, src, shape, ndim, src_is_device, (hipStream_t)stream);
+    DSD_CATCH
+}
+
+int dsd_set_timestep_freqs(dsd_handle* h, const float* freqs_host, int n) {
+    DSD_TRY
+    DSD_CHECK(h && !h->is_block && freqs_host, "null argument");
+    DSD_CHECK(n == h->cfg.model_channels / 2, "expected %d frequencies, got %d", h->cfg.model_channels / 2, n);
+    set_device(h->device);
+    if (!h->freqs) DSD_HIP(hipMalloc((void**)&h->freqs, (size_t)n * sizeof(float)));
+    DSD_HIP(hipMemcpy(h->freqs, freqs_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
     DSD_CATCH
 }
 
@@ -273,11 +287,11 @@ int dsd_sample(dsd_handle* h, const dsd_schedule* sc, const float* cond, int Cc,
 }
 
 int dsd_op_sampler_update(const dsd_schedule* sc, int k, const float* model_out, float* x, const float* noise,
-                          uint64_t philox_seed, int B, int H, int W, void* stream) {
+                          uint64_t philox_seed, int B, int H, int W, float* pred_xstart, void* stream) {
     DSD_TRY
     check_schedule(sc);
     DSD_CHECK(k >= 0 && k < sc->steps && model_out && x, "bad argument");
-    sampler_update(step_coef(sc, k), model_out, x, noise, philox_seed, (uint64_t)k, B, H * W, (hipStream_t)stream);
+    sampler_update(step_coef(sc, k), model_out, x, noise, philox_seed, (uint64_t)k, B, H * W, (hipStream_t)stream, pred_xstart);
     DSD_CATCH
 }
 

@@ -51,7 +51,8 @@ struct AttnArgs {
 void attention(const AttnArgs& a, hipStream_t s);
 
 // ---------------------------------------------------------------- misc.hip
-void timestep_embedding(const void* t, int t_is_float, int N, int dim, float* y, hipStream_t s);
+void timestep_embedding(const void* t, int t_is_float, int N, int dim, float* y, hipStream_t s,
+                        const float* freqs = nullptr);
 void linear(const float* x, int N, int K, int ldx, const float* w, const float* bias, int O, int act_in, float* y,
             int ldy, hipStream_t s);
 void se_scale(const float* x, int N, int HW, int C, const float* w1, const float* w2, int Cr, float* y, hipStream_t s);
@@ -73,7 +74,7 @@ struct StepCoef {
 };
 // model_out: [B,Cm,HW] (Cm = 1, or 2 with learned_range); x in/out [B,1,HW]; noise [B,1,HW] or null (Philox)
 void sampler_update(const StepCoef& sc, const float* model_out, float* x, const float* noise, uint64_t seed,
-                    uint64_t step, int B, int HW, hipStream_t s);
+                    uint64_t step, int B, int HW, hipStream_t s, float* x0_out = nullptr);
 void philox_normal(float* y, int64_t n, uint64_t seed, uint64_t step, hipStream_t s);
 void fill_t(float* t, int B, float v, hipStream_t s);
 

@@ -8,7 +8,8 @@ __device__ __forceinline__ float silu_f(float v) { return v / (1.f + expf(-v)); 
 
 // timestep_embedding, ldm/modules/diffusionmodules/util.py:161-181: cat[cos(t*f), sin(t*f)], f_k = exp(-ln(1e4)*k/half)
 // evaluated like the reference in fp32 (the fp32 argument is formed with fp32 ops, exp itself is taken in fp64 and rounded once).
-__global__ void timestep_embedding_kernel(const void* __restrict__ t, int t_is_float, int N, int dim, float* __restrict__ y) {
+__global__ void timestep_embedding_kernel(const void* __restrict__ t, int t_is_float, int N, int dim,
+                                          const float* __restrict__ freqs, float* __restrict__ y) {
     const int half = dim / 2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N * half) return;
@@ -16,17 +17,17 @@ __global__ void timestep_embedding_kernel(const void* __restrict__ t, int t_is_f
     const float tv = t_is_float ? ((const float*)t)[n] : (float)((const long long*)t)[n];
     const float neg_log = -9.210340371976184f;  // (float)(-math.log(10000))
     const float arg = (neg_log * (float)k) / (float)half;
-    const float f = (float)exp((double)arg);
+    const float f = freqs ? freqs[k] : (float)exp((double)arg);   // host table (bit-identical to the caller's torch.exp) if given
     const float a = tv * f;
     y[(int64_t)n * dim + k] = cosf(a);
     y[(int64_t)n * dim + half + k] = sinf(a);
     if ((dim & 1) && k == 0) y[(int64_t)n * dim + dim - 1] = 0.f;
 }
 
-void timestep_embedding(const void* t, int t_is_float, int N, int dim, float* y, hipStream_t s) {
+void timestep_embedding(const void* t, int t_is_float, int N, int dim, float* y, hipStream_t s, const float* freqs) {
     const int total = N * (dim / 2);
     if (total == 0) return;
-    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t, t_is_float, N, dim, y);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, t, t_is_float, N, dim, freqs, y);
     check_launch("timestep_embedding");
 }
 

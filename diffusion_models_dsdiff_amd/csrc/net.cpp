@@ -332,11 +332,12 @@ void dsd::net_declare_params(dsd_handle* h) {
         off = (off + 255) & ~(size_t)255;
     }
     h->slab_bytes = off + 256;
-    DSD_HIP(hipMalloc((void**)&h->slab, h->slab_bytes));
+    if (h->device >= 0) DSD_HIP(hipMalloc((void**)&h->slab, h->slab_bytes));  // device < 0: table-only handle (host-side checks)
 }
 
 void dsd::net_set_param(dsd_handle* h, const char* name, const float* src, const int64_t* shape, int ndim, int src_is_device,
                         hipStream_t s) {
+    DSD_CHECK(h->device >= 0 && h->slab, "this handle was created without a device (table only)");
     auto it = h->pidx.find(name);
     DSD_CHECK(it != h->pidx.end(), "unexpected parameter '%s'", name);
     Param& p = h->params[it->second];
@@ -375,12 +376,13 @@ void dsd::net_set_param(dsd_handle* h, const char* name, const float* src, const
 }
 
 void dsd::net_free(dsd_handle* h) {
-    if (h->slab) hipFree(h->slab);
-    if (h->staging) hipFree(h->staging);
-    if (h->arena) hipFree(h->arena);
-    if (h->tbuf) hipFree(h->tbuf);
-    if (h->mout) hipFree(h->mout);
-    if (h->zplane) hipFree(h->zplane);
+    if (h->slab) (void)hipFree(h->slab);
+    if (h->staging) (void)hipFree(h->staging);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->tbuf) (void)hipFree(h->tbuf);
+    if (h->mout) (void)hipFree(h->mout);
+    if (h->zplane) (void)hipFree(h->zplane);
+    if (h->freqs) (void)hipFree(h->freqs);
 }
 
 // =============================================================================================== builder
@@ -779,7 +781,7 @@ void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats) {
             float* e1p = reinterpret_cast<float*>(hd->arena + e1o);
             float* ep = reinterpret_cast<float*>(hd->arena + eo);
             float* ap = reinterpret_cast<float*>(hd->arena + ao);
-            timestep_embedding(hd->io.t, hd->io.t_is_float, B, mc, tp, s);
+            timestep_embedding(hd->io.t, hd->io.t_is_float, B, mc, tp, s, hd->freqs);
             linear(tp, B, mc, mc, w0, b0, ted, ACT_NONE, e1p, ted, s);
             linear(e1p, B, ted, ted, w2, b2, ted, ACT_SILU, ep, ted, s);
             linear(ep, B, ted, ted, wall, ball, etot, ACT_SILU, ap, etot, s);
@@ -1000,6 +1002,7 @@ void dsd::net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int
     if (p.valid && p.B == B && p.C == C && p.H == H && p.W == W && p.zero_al_l == zero_al_l && p.want_feats == want_feats &&
         p.aux_len == aux_len && p.aux_len2 == aux_len2)
         return;
+    DSD_CHECK(h->device >= 0, "this handle was created without a device (table only)");
     for (const auto& prm : h->params) DSD_CHECK(prm.set, "parameter '%s' has not been set", prm.name.c_str());
     DSD_CHECK(B >= 1 && H >= 1 && W >= 1, "empty input");
     p = Plan{};

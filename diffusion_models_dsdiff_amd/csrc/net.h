@@ -91,6 +91,7 @@ struct dsd_handle {
     float* tbuf = nullptr;     // [B] timesteps (fp32)
     float* mout = nullptr;     // [B,out_ch,H,W]
     float* zplane = nullptr;   // [H*W] zeros
+    float* freqs = nullptr;    // [model_channels/2] optional timestep-embedding frequency table (host-supplied)
     size_t tbuf_cap = 0, mout_cap = 0, zplane_cap = 0;
 
     float* P(const std::string& name) const;

@@ -63,6 +63,7 @@ const char* dsd_last_error(void);
 int dsd_device_info(int device, char* name, int name_len, int* n_cu, int64_t* hbm_bytes);
 
 /* ---- model handle ------------------------------------------------------------------------ */
+/* device < 0 creates a table-only handle (parameter names/shapes, no GPU needed; compute calls fail). */
 int dsd_create(const dsd_config* cfg, int device, dsd_handle** out);
 void dsd_destroy(dsd_handle* h);
 
@@ -73,6 +74,11 @@ int dsd_param_info(dsd_handle* h, int idx, const char** name, int64_t shape[4], 
  * 3x3 conv weights are re-packed OIHW -> OHWI on device. */
 int dsd_set_param(dsd_handle* h, const char* name, const float* src, const int64_t* shape, int ndim,
                   int src_is_device, void* stream);
+/* Optional: the sinusoidal-embedding frequency table exp(-ln(1e4)*k/half), k < model_channels/2
+ * (util.py:172-174), as evaluated by the caller's own fp32 exp.  sin/cos of t*f with t up to 1e3 amplify a
+ * 1-ulp difference in f to ~6e-5, so a host that wants bit-identical arguments supplies its table; without
+ * it the library evaluates exp in fp64 and rounds once. */
+int dsd_set_timestep_freqs(dsd_handle* h, const float* freqs_host, int n);
 /* 0 if every parameter has been set, else -1 with the first missing name in dsd_last_error(). */
 int dsd_params_ready(dsd_handle* h);
 
@@ -126,9 +132,10 @@ typedef struct dsd_schedule {
  * iterations (n_steps<=0 = all) so a caller can time or checkpoint part of the chain. */
 int dsd_sample(dsd_handle* h, const dsd_schedule* sched, const float* cond, int Cc, float* x, const float* noise,
                uint64_t philox_seed, int B, int H, int W, int first_step, int n_steps, void* stream);
-/* The fused sampler update alone (one step), for kernel-level tests: model_out [B,Cm,H,W]. */
+/* The fused sampler update alone (iteration k): model_out [B,Cm,H,W]; x updated in place; pred_xstart
+ * (optional, [B,1,H,W]) receives the clipped x_0 prediction (the reference's out["pred_xstart"]). */
 int dsd_op_sampler_update(const dsd_schedule* sched, int k, const float* model_out, float* x, const float* noise,
-                          uint64_t philox_seed, int B, int H, int W, void* stream);
+                          uint64_t philox_seed, int B, int H, int W, float* pred_xstart, void* stream);
 
 /* ---- single blocks (own parameter namespace, names relative to the block) ----------------- */
 enum { DSD_BLOCK_RES = 0, DSD_BLOCK_ATTN = 1, DSD_BLOCK_UPSAMPLE = 2, DSD_BLOCK_DOWNSAMPLE = 3,

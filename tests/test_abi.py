@@ -1,0 +1,90 @@
+"""The C-ABI library loads and exports every symbol include/dsdiff.h declares (no compute calls, no GPU)."""
+import ctypes as C
+import os
+import re
+
+from diffusion_models_dsdiff_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "dsdiff.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dsd_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported():
+    L = _lib.lib()
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/dsdiff.h but not exported by libdsdiff.so"
+    assert sorted(_lib.EXPORTS) == names, "python binding list out of sync with the header"
+
+
+def test_struct_layouts_match_header():
+    # dsd_config: 3 + 1 + 8 + 8 + 1 + 8 + 7 int32 ; dsd_schedule: 5 int32 + float + 3 pointers
+    assert C.sizeof(_lib.DsdConfig) == 4 * (3 + 1 + 8 + 8 + 1 + 8 + 7)
+    assert C.sizeof(_lib.DsdSchedule) == 24 + 3 * C.sizeof(C.c_void_p)
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        return
+    try:
+        _lib.require_gpu(0)
+    except _lib.DsdError as e:
+        assert "device" in str(e).lower() or "hip" in str(e).lower()
+    else:
+        raise AssertionError("require_gpu must raise without a GPU")
+
+
+def test_parameter_table_matches_reference_names():
+    """Table-only handle (device = -1): names/shapes equal the reference state_dict stored in the golden fixture."""
+    import json
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "model.npz"))
+    for key in ("tiny", "tinyfilm"):
+        params = json.loads(str(g[key + "_cfg"]))
+        cfg = _lib.DsdConfig()
+        cfg.in_channels, cfg.model_channels, cfg.out_channels = params["in_channels"], params["model_channels"], params["out_channels"]
+        cm = params["channel_mult"]
+        nrb = params["num_res_blocks"]
+        nrb = [nrb] * len(cm) if isinstance(nrb, int) else nrb
+        cfg.n_levels = len(cm)
+        for i in range(len(cm)):
+            cfg.channel_mult[i], cfg.num_res_blocks[i] = cm[i], nrb[i]
+        ar = params["attention_resolutions"]
+        cfg.n_attention_resolutions = len(ar)
+        for i, a in enumerate(ar):
+            cfg.attention_resolutions[i] = a
+        cfg.num_heads = params.get("num_heads", -1)
+        cfg.num_head_channels = params.get("num_head_channels", -1)
+        cfg.num_heads_upsample = -1
+        cfg.use_scale_shift_norm = int(params.get("use_scale_shift_norm", False))
+        cfg.resblock_updown = int(params.get("resblock_updown", False))
+        cfg.use_new_attention_order = int(params.get("use_new_attention_order", False))
+        cfg.legacy = int(params.get("legacy", True))
+        h = C.c_void_p()
+        L = _lib.lib()
+        _lib.check(L.dsd_create(C.byref(cfg), -1, C.byref(h)))
+        got = {}
+        name, shape, ndim = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+        for i in range(L.dsd_param_count(h)):
+            _lib.check(L.dsd_param_info(h, i, C.byref(name), shape, C.byref(ndim)))
+            got[name.value.decode()] = tuple(shape[k] for k in range(ndim.value))
+        L.dsd_destroy(h)
+        ref = {n: tuple(s) for n, s in json.loads(str(g[key + "_params"]))}
+        assert got == ref
+
+
+def test_bad_config_is_rejected():
+    cfg = _lib.DsdConfig()
+    cfg.in_channels, cfg.model_channels, cfg.out_channels, cfg.n_levels = 3, 32, 1, 1
+    cfg.channel_mult[0], cfg.num_res_blocks[0] = 1, 1
+    cfg.num_heads, cfg.num_head_channels, cfg.num_heads_upsample = -1, 16, -1
+    h = C.c_void_p()
+    assert _lib.lib().dsd_create(C.byref(cfg), -1, C.byref(h)) != 0
+    assert b"in_channels" in _lib.lib().dsd_last_error()

@@ -1,0 +1,165 @@
+"""Block- and model-level parity (GPU) through the C ABI vs reference-generated fixtures and the oracle.
+
+Tolerances: single blocks rel-L2 <= 3e-6; whole tiny model <= 1e-5 (fp32 re-association over ~60 layers;
+the 1e-4 north-star bar applies to the final sampled image).
+"""
+import json
+
+import pytest
+import torch
+
+from oracle import unet as O
+from util import golden, fixture_params, rel_l2, randn
+
+pytestmark = pytest.mark.gpu
+TOL_BLOCK = 3e-6
+TOL_MODEL = 5e-6
+# C_in = 2 on the TINY model only: the two zero-input streams (model.py:654-658) make the first conv emit a
+# per-channel constant, and with model_channels = 32 a GroupNorm group is ONE channel -> zero variance,
+# rstd = 1/sqrt(eps) = 316.  y = x*scale + (beta - mean*scale) then cancels catastrophically in fp32 in the
+# reference (ATen's CPU kernel uses the same scale/bias form) and here alike; the two round differently, which
+# shows up as ~1e-5 instead of ~2e-6.  The yaml config (10 channels per group) never has a zero-variance group.
+TOL_MODEL_DEGENERATE = 5e-5
+
+
+def load(mod, sd):
+    missing = mod.load_state_dict(sd, strict=True)
+    return mod.cuda() if False else mod
+
+
+@pytest.fixture(scope="module")
+def B():
+    from diffusion_models_dsdiff_amd import blocks, _lib
+    _lib.require_gpu(0)
+    return blocks
+
+
+def test_resblocks_golden(B):
+    g = golden("ops")
+    emb = randn((2, 128), 20).cuda()
+    cases = [("res_same", dict(channels=64, out_channels=64), (2, 64, 16, 16), 21),
+             ("res_skip", dict(channels=32, out_channels=64), (2, 32, 16, 16), 22),
+             ("res_film", dict(channels=32, out_channels=64, use_scale_shift_norm=True), (2, 32, 16, 16), 23),
+             ("res_down", dict(channels=64, out_channels=64, use_scale_shift_norm=True, down=True), (2, 64, 16, 16), 24),
+             ("res_up", dict(channels=64, out_channels=64, use_scale_shift_norm=True, up=True), (2, 64, 8, 8), 25)]
+    for key, kw, shp, xs in cases:
+        m = B.ResBlock(emb_channels=128, dropout=0.0, **kw)
+        m.load_state_dict(fixture_params(g, key), strict=True)
+        y = m(randn(shp, xs).cuda(), emb)
+        assert rel_l2(y, g[key + "_y"]) < TOL_BLOCK, key
+
+
+def test_attention_blocks_golden(B):
+    g = golden("ops")
+    for key, kw, shp, xs in [("attn_new_c64_t64", dict(channels=64, num_head_channels=16, use_new_attention_order=True), (2, 64, 8, 8), 30),
+                             ("attn_legacy_c64_t64", dict(channels=64, num_head_channels=32, use_new_attention_order=False), (2, 64, 8, 8), 31),
+                             ("attn_new_c64_t4", dict(channels=64, num_head_channels=32, use_new_attention_order=True), (1, 64, 2, 2), 32),
+                             ("attn_new_c128_t1024", dict(channels=128, num_head_channels=32, use_new_attention_order=True), (1, 128, 32, 32), 33),
+                             ("attn_new_c96_d48_t144", dict(channels=96, num_head_channels=48, use_new_attention_order=True), (1, 96, 12, 12), 34)]:
+        m = B.AttentionBlock(**kw)
+        m.load_state_dict(fixture_params(g, key), strict=True)
+        assert rel_l2(m(randn(shp, xs).cuda()), g[key + "_y"]) < TOL_BLOCK, key
+
+
+def test_resample_se_disentangle_golden(B):
+    g = golden("ops")
+    m = B.Upsample(32, True)
+    m.load_state_dict(fixture_params(g, "upsample"), strict=True)
+    assert rel_l2(m(randn((2, 32, 8, 8), 40).cuda()), g["upsample_y"]) < TOL_BLOCK
+    m = B.Downsample(32, True)
+    m.load_state_dict(fixture_params(g, "downsample"), strict=True)
+    assert rel_l2(m(randn((2, 32, 16, 16), 41).cuda()), g["downsample_y"]) < TOL_BLOCK
+    m = B.SE_Attention(64, reduction=8)
+    m.load_state_dict(fixture_params(g, "se_attention"), strict=True)
+    assert rel_l2(m(randn((2, 64, 4, 4), 50).cuda()), g["se_attention_y"]) < TOL_BLOCK
+    m = B.FeatureDisentangle(64, 32)
+    m.load_state_dict(fixture_params(g, "disentangle"), strict=True)
+    assert rel_l2(m(randn((2, 64, 4, 4), 51).cuda()), g["disentangle_y"]) < TOL_BLOCK
+
+
+def test_cross_attention_variant_golden(B):
+    """pinned at block level with token context [B,N,C]."""
+    g = golden("xattn")
+    x, ctx, ctx2 = randn((2, 16, 64), 60).cuda(), randn((2, 9, 32), 61).cuda(), randn((2, 5, 32), 63).cuda()
+    m = B.CrossAttention(64, context_dim=32, heads=4, dim_head=16)
+    m.load_state_dict(fixture_params(g, "xattn"), strict=True)
+    assert rel_l2(m(x, context=ctx), g["xattn_y"]) < TOL_BLOCK
+    m = B.CrossAttention(64, heads=4, dim_head=16)
+    m.load_state_dict(fixture_params(g, "selfattn"), strict=True)
+    assert rel_l2(m(x), g["selfattn_y"]) < TOL_BLOCK
+    m = B.FeedForward(64, glu=True)
+    m.load_state_dict(fixture_params(g, "ff_geglu"), strict=True)
+    assert rel_l2(m(x), g["ff_geglu_y"]) < TOL_BLOCK
+    m = B.BasicTransformerBlock(64, 4, 16, context_dim=32, checkpoint=False)
+    m.load_state_dict(fixture_params(g, "btb"), strict=True)
+    assert rel_l2(m(x, context=ctx), g["btb_y"]) < TOL_BLOCK
+    xs = randn((2, 64, 4, 4), 62).cuda()
+    m = B.SpatialTransformer(64, 4, 16, depth=2, context_dim=[32, 32], use_checkpoint=False)
+    m.load_state_dict(fixture_params(g, "spatial_tf"), strict=True)
+    assert rel_l2(m(xs, context=[ctx, ctx2]), g["spatial_tf_y"]) < TOL_BLOCK
+    m = B.SpatialTransformer(64, 4, 16, depth=1, context_dim=[32], use_linear=True, use_checkpoint=False)
+    m.load_state_dict(fixture_params(g, "spatial_tf_lin"), strict=True)
+    assert rel_l2(m(xs, context=[ctx]), g["spatial_tf_lin_y"]) < TOL_BLOCK
+
+
+def tiny_native(key):
+    from diffusion_models_dsdiff_amd.UNet_DS_Diff.model import DSUnetModel
+    g = golden("model")
+    params = json.loads(str(g[key + "_cfg"]))
+    m = DSUnetModel(**params)
+    ref_names = [n for n, _ in json.loads(str(g[key + "_params"]))]
+    assert sorted(m.state_dict().keys()) == sorted(ref_names)          # reference checkpoints load by name
+    m.load_state_dict(fixture_params(g, key), strict=True)
+    return g, m, params
+
+
+@pytest.mark.parametrize("key", ["tiny", "tinyfilm"])
+def test_model_forward_golden(key):
+    g, m, params = tiny_native(key)
+    cfg = O.UNetConfig.from_params(params)
+    sd = fixture_params(g, key)
+    for C, xs in ((2, 70), (4, 71)):
+        x = randn((2, C, 32, 32), xs)
+        y, feats = m(x.cuda(), torch.tensor([999, 17]).cuda())
+        assert y.shape == (2, params["out_channels"], 32, 32)
+        tol = TOL_MODEL if C == 4 else TOL_MODEL_DEGENERATE
+        assert rel_l2(y, g[f"{key}_c{C}_int_y"]) < tol
+        for fk, fl in feats.items():
+            assert rel_l2(torch.stack(fl), g[f"{key}_c{C}_feat_{fk}"]) < tol, fk
+        y2, _ = m(x.cuda(), torch.tensor([499.5, 20.0]).cuda())
+        assert rel_l2(y2, g[f"{key}_c{C}_float_y"]) < tol
+        # and against the oracle run live on the same inputs
+        yo, _ = O.unet_forward(cfg, sd, x, torch.tensor([999, 17]))
+        assert rel_l2(y, yo) < tol
+
+
+def test_model_default_init_is_zero_like_reference():
+    """zero_module() sites make the reference's output identically 0 at default init (SURVEY.md headline fact 3)."""
+    from diffusion_models_dsdiff_amd.UNet_DS_Diff.model import DSUnetModel
+    params = json.loads(str(golden("model")["tiny_cfg"]))
+    torch.manual_seed(0)
+    m = DSUnetModel(**params)
+    y, _ = m(randn((1, 2, 32, 32), 1).cuda(), torch.tensor([5]).cuda())
+    assert float(y.abs().max()) == 0.0
+
+
+def test_model_other_shapes_and_errors():
+    from diffusion_models_dsdiff_amd import _lib
+    g, m, params = tiny_native("tiny")
+    cfg, sd = O.UNetConfig.from_params(params), fixture_params(g, "tiny")
+    for shp in [(1, 2, 64, 32), (3, 4, 16, 48), (5, 2, 8, 8)]:          # ragged batch, non-square, minimum size
+        x = randn(shp, 7)
+        t = torch.arange(shp[0]) * 37 + 3
+        y, _ = m(x.cuda(), t.cuda())
+        yo, _ = O.unet_forward(cfg, sd, x, t)
+        assert rel_l2(y, yo) < (TOL_MODEL if shp[1] == 4 else TOL_MODEL_DEGENERATE), shp
+    with pytest.raises(_lib.DsdError):                                   # H not a multiple of 2^(levels-1)
+        m(randn((1, 2, 30, 32), 1).cuda(), torch.tensor([1]).cuda())
+    with pytest.raises(_lib.DsdError):                                   # 3 channels: neither branch of model.py:654-663
+        m(randn((1, 3, 32, 32), 1).cuda(), torch.tensor([1]).cuda())
+    with pytest.raises(_lib.DsdError):                                   # CPU tensors: no CPU fallback
+        m(randn((1, 2, 32, 32), 1), torch.tensor([1]))
+    with pytest.raises(RuntimeError):                                    # wrong shape in a checkpoint
+        bad = dict(sd)
+        bad["out.2.weight"] = torch.zeros(1, 16, 3, 3)
+        m.load_state_dict(bad, strict=True)
