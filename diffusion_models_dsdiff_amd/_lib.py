@@ -24,7 +24,7 @@ PRED_EPS, PRED_X0, PRED_V = 0, 1, 2
 EXPORTS = [
     "dsd_last_error", "dsd_device_info", "dsd_create", "dsd_destroy", "dsd_param_count", "dsd_param_info",
     "dsd_set_param", "dsd_set_timestep_freqs", "dsd_params_ready", "dsd_plan", "dsd_workspace_bytes", "dsd_plan_launches", "dsd_plan_flops",
-    "dsd_forward", "dsd_sample", "dsd_op_sampler_update", "dsd_block_create", "dsd_block_forward", "dsd_op_conv2d",
+    "dsd_profile_enable", "dsd_profile_count", "dsd_profile_get", "dsd_forward", "dsd_sample", "dsd_op_sampler_update", "dsd_block_create", "dsd_block_forward", "dsd_op_conv2d",
     "dsd_op_group_norm", "dsd_op_qkv_attention", "dsd_op_timestep_embedding", "dsd_op_linear", "dsd_op_philox_normal",
 ]
 
@@ -72,6 +72,9 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise DsdError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                        f"(or make -C {CSRC}); there is no CPU fallback")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; load torch FIRST so both share that one HIP runtime
+    # (loading /opt/rocm's copy first leaves torch with "No HIP GPUs are available").
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32p = C.c_void_p, C.c_int, C.c_int64, C.c_void_p
     L.dsd_last_error.restype = C.c_char_p
@@ -90,6 +93,10 @@ def lib() -> C.CDLL:
     L.dsd_plan_launches.argtypes = [vp]
     L.dsd_plan_flops.argtypes = [vp]
     L.dsd_plan_flops.restype = C.c_double
+    L.dsd_profile_enable.argtypes = [vp, i32]
+    L.dsd_profile_count.argtypes = [vp]
+    L.dsd_profile_get.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     L.dsd_forward.argtypes = [vp, f32p, vp, i32, i32, i32, i32, i32, f32p, C.POINTER(vp), vp]
     L.dsd_sample.argtypes = [vp, C.POINTER(DsdSchedule), f32p, i32, f32p, f32p, C.c_uint64, i32, i32, i32, i32, i32, vp]
     L.dsd_op_sampler_update.argtypes = [C.POINTER(DsdSchedule), i32, f32p, f32p, f32p, C.c_uint64, i32, i32, i32, f32p, vp]

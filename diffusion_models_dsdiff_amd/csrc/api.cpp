@@ -211,6 +211,32 @@ int dsd_forward(dsd_handle* h, const float* x, const void* t, int t_is_float, in
     DSD_CATCH
 }
 
+int dsd_profile_enable(dsd_handle* h, int on) {
+    DSD_TRY
+    DSD_CHECK(h, "null handle");
+    h->profiling = on != 0;
+    if (on) {
+        h->prof_names.clear();
+        h->prof_runs = 0;
+    }
+    DSD_CATCH
+}
+
+int dsd_profile_count(dsd_handle* h) { return h ? (int)h->prof_names.size() : -1; }
+
+int dsd_profile_get(dsd_handle* h, int idx, const char** kind, double* total_ms, double* flops, double* bytes,
+                    int64_t* calls, int* runs) {
+    DSD_TRY
+    DSD_CHECK(h && idx >= 0 && idx < (int)h->prof_names.size(), "profile index out of range");
+    if (kind) *kind = h->prof_names[idx].c_str();
+    if (total_ms) *total_ms = h->prof_ms[idx];
+    if (flops) *flops = h->prof_flops[idx];
+    if (bytes) *bytes = h->prof_bytes[idx];
+    if (calls) *calls = h->prof_calls[idx];
+    if (runs) *runs = h->prof_runs;
+    DSD_CATCH
+}
+
 int dsd_block_forward(dsd_handle* h, const float* x, int B, int C, int H, int W, const float* aux, int aux_len,
                       const float* aux2, int aux_len2, float* out, void* stream) {
     DSD_TRY

@@ -315,6 +315,15 @@ static int pick_nt(int Cout, int tiles_m) {
     return best;
 }
 
+const char* conv2d_variant(const ConvArgs& a) {
+    const int Ktot = a.ks * a.ks * a.Cin;
+    if (a.Cin % 4 != 0 || Ktot < 32) return (a.Cout % 4 == 0 && (size_t)Ktot * a.Cout * 4 <= 60 * 1024) ? "conv_direct_lds" : "conv_scalar";
+    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
+    const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
+    static const char* names[6] = {"", "conv_mfma<1>", "conv_mfma<2>", "conv_mfma<3>", "conv_mfma<4>", "conv_mfma<5>"};
+    return names[pick_nt(a.Cout, cdiv((int64_t)a.N * OH * OW, BM))];
+}
+
 void conv2d(ConvArgs a, hipStream_t s) {
     DSD_CHECK(a.ks == 1 || a.ks == 3, "conv2d: kernel size %d unsupported", a.ks);
     DSD_CHECK(a.stride == 1 || a.stride == 2, "conv2d: stride %d unsupported", a.stride);

@@ -23,6 +23,7 @@ struct ConvArgs {
 };
 void conv2d(ConvArgs a, hipStream_t s);
 double conv2d_flops(const ConvArgs& a);
+const char* conv2d_variant(const ConvArgs& a);   // name of the kernel conv2d() will launch for these arguments
 void pack_ohwi(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, hipStream_t s);
 
 // ---------------------------------------------------------------- norm.hip

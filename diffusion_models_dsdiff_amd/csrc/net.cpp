@@ -414,9 +414,20 @@ struct Builder {
     }
     size_t alloc_raw(size_t bytes) { return ar.alloc(bytes); }
     void release_raw(size_t off, size_t bytes) { ar.release(off, bytes); }
-    void op(std::function<void(hipStream_t)> f, int launches = 1) {
+    void op(std::function<void(hipStream_t)> f, int launches = 1, const std::string& kind = "misc", double flops = 0.0,
+            double bytes = 0.0) {
         plan.ops.push_back(std::move(f));
         plan.launches += launches;
+        int k = -1;
+        for (size_t i = 0; i < plan.kind_names.size(); ++i)
+            if (plan.kind_names[i] == kind) k = (int)i;
+        if (k < 0) {
+            k = (int)plan.kind_names.size();
+            plan.kind_names.push_back(kind);
+        }
+        plan.op_kind.push_back(k);
+        plan.op_flops.push_back(flops);
+        plan.op_bytes.push_back(bytes);
     }
     float* W(const std::string& n) { return hd->P(n); }
     bool has(const std::string& n) { return hd->pidx.count(n) != 0; }
@@ -460,7 +471,8 @@ struct Builder {
             }
             if (has_res) c.res = reinterpret_cast<const float*>(h->arena + roff);
             conv2d(c, s);
-        });
+        }, 1, conv2d_variant(a), conv2d_flops(a),
+           4.0 * ((double)x.n * x.h * x.w * x.c + (double)cout * x.c * ks * ks + (double)x.n * OH * OW * cout * (has_res ? 2 : 1)));
         return y;
     }
 
@@ -480,16 +492,19 @@ struct Builder {
         EmbRef e;
         if (film) e = *film;
         dsd_handle* h = hd;
+        const double tbytes = 4.0 * N * HW * C;
         op([=](hipStream_t s) {
-            const float* xp = reinterpret_cast<const float*>(h->arena + xoff);
-            double* part = reinterpret_cast<double*>(h->arena + poff);
-            float* sc = reinterpret_cast<float*>(h->arena + scoff);
-            float* sh = reinterpret_cast<float*>(h->arena + shoff);
-            gn_stats(xp, N, HW, C, part, nchunk, s);
+            gn_stats(reinterpret_cast<const float*>(h->arena + xoff), N, HW, C, reinterpret_cast<double*>(h->arena + poff), nchunk, s);
+        }, 1, "gn_stats", 0.0, tbytes);
+        op([=](hipStream_t s) {
             const float* fp = e.valid ? reinterpret_cast<const float*>(h->arena + e.arena_off) + e.col : nullptr;
-            gn_finalize(part, nchunk, N, HW, C, gamma, beta, eps, fp, e.stride, sc, sh, s);
-            affine_act(xp, N, HW, C, sc, sh, act, reinterpret_cast<float*>(h->arena + yoff), s);
-        }, 3);
+            gn_finalize(reinterpret_cast<double*>(h->arena + poff), nchunk, N, HW, C, gamma, beta, eps, fp, e.stride,
+                        reinterpret_cast<float*>(h->arena + scoff), reinterpret_cast<float*>(h->arena + shoff), s);
+        }, 1, "gn_finalize");
+        op([=](hipStream_t s) {
+            affine_act(reinterpret_cast<const float*>(h->arena + xoff), N, HW, C, reinterpret_cast<float*>(h->arena + scoff),
+                       reinterpret_cast<float*>(h->arena + shoff), act, reinterpret_cast<float*>(h->arena + yoff), s);
+        }, 1, act == ACT_SILU ? "gn_silu_apply" : "gn_apply", 0.0, 2.0 * tbytes);
         release_raw(poff, pbytes);
         release_raw(scoff, sbytes);
         release_raw(shoff, sbytes);
@@ -572,7 +587,7 @@ struct Builder {
                 r.q = base + qo; r.k = base + ko; r.v = base + vo;
                 r.out = reinterpret_cast<float*>(h->arena + aoff);
                 attention(r, s);
-            });
+            }, 1, "attention", 4.0 * x.n * heads * (double)T * T * d);
         }
         release(qkv);
         Tn out = conv(pre(p, "proj_out"), a, C, 1, 1, false, nullptr, &x);
@@ -620,7 +635,7 @@ struct Builder {
             const float* p[4] = {nullptr, nullptr, nullptr, nullptr};
             for (int i = 0; i < nsrc; ++i) p[i] = reinterpret_cast<const float*>(h->arena + o[i]);
             avg_into(p[0], p[1], p[2], p[3], div, pixels, C, reinterpret_cast<float*>(h->arena + doff), dstC, coff, act, s);
-        });
+        }, 1, nsrc == 4 ? "skip_avg4_concat" : "concat_copy", 0.0, 4.0 * pixels * C * (nsrc + 1));
     }
 
     // TimestepEmbedSequential.forward, openaimodel.py:80-90.  Consumes (releases) x unless keep_input.
@@ -785,7 +800,7 @@ void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats) {
             linear(tp, B, mc, mc, w0, b0, ted, ACT_NONE, e1p, ted, s);
             linear(e1p, B, ted, ted, w2, b2, ted, ACT_SILU, ep, ted, s);
             linear(ep, B, ted, ted, wall, ball, etot, ACT_SILU, ap, etot, s);
-        }, 4);
+        }, 4, "time_embed_mlp", 2.0 * B * ((double)mc * ted + (double)ted * ted + (double)ted * etot));
     }
     b.release(temb); b.release(e1); b.release(emb);
     // column of each ResBlock inside emb_all = position of its bias in the contiguous bias region (declaration order)
@@ -1027,5 +1042,40 @@ void dsd::net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int
 
 void dsd::net_run(dsd_handle* h, hipStream_t s) {
     DSD_CHECK(h->plan.valid, "no plan");
-    for (auto& f : h->plan.ops) f(s);
+    Plan& p = h->plan;
+    if (!h->profiling) {
+        for (auto& f : p.ops) f(s);
+        return;
+    }
+    // profiling pass: one event pair per op on the launch stream, read back after a stream sync
+    const size_t n = p.ops.size();
+    while (h->ev.size() < 2 * n) {
+        hipEvent_t e;
+        DSD_HIP(hipEventCreate(&e));
+        h->ev.push_back(e);
+    }
+    for (size_t i = 0; i < n; ++i) {
+        DSD_HIP(hipEventRecord(h->ev[2 * i], s));
+        p.ops[i](s);
+        DSD_HIP(hipEventRecord(h->ev[2 * i + 1], s));
+    }
+    DSD_HIP(hipStreamSynchronize(s));
+    if (h->prof_names != p.kind_names) {
+        h->prof_names = p.kind_names;
+        h->prof_ms.assign(p.kind_names.size(), 0.0);
+        h->prof_flops.assign(p.kind_names.size(), 0.0);
+        h->prof_bytes.assign(p.kind_names.size(), 0.0);
+        h->prof_calls.assign(p.kind_names.size(), 0);
+        h->prof_runs = 0;
+    }
+    for (size_t i = 0; i < n; ++i) {
+        float ms = 0.f;
+        DSD_HIP(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+        const int k = p.op_kind[i];
+        h->prof_ms[k] += ms;
+        h->prof_flops[k] += p.op_flops[i];
+        h->prof_bytes[k] += p.op_bytes[i];
+        h->prof_calls[k] += 1;
+    }
+    h->prof_runs += 1;
 }

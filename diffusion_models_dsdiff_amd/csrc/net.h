@@ -57,6 +57,10 @@ struct Plan {
     int aux_len = 0, aux_len2 = 0;
     bool valid = false;
     std::vector<std::function<void(hipStream_t)>> ops;
+    std::vector<int> op_kind;        // index into kind_names
+    std::vector<double> op_flops;    // algorithmic FLOPs of the op (0 for memory-bound ops)
+    std::vector<double> op_bytes;    // algorithmic bytes (read+write) of the op (0 if not tracked)
+    std::vector<std::string> kind_names;
     size_t arena_bytes = 0;
     double flops = 0.0;
     int launches = 0;
@@ -92,6 +96,13 @@ struct dsd_handle {
     float* mout = nullptr;     // [B,out_ch,H,W]
     float* zplane = nullptr;   // [H*W] zeros
     float* freqs = nullptr;    // [model_channels/2] optional timestep-embedding frequency table (host-supplied)
+    // per-kernel profiling (dsd_profile_*): hipEvents around every op of the plan on the caller's stream
+    bool profiling = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<double> prof_ms, prof_flops, prof_bytes;   // per kind
+    std::vector<int64_t> prof_calls;
+    std::vector<std::string> prof_names;
+    int prof_runs = 0;
     size_t tbuf_cap = 0, mout_cap = 0, zplane_cap = 0;
 
     float* P(const std::string& name) const;

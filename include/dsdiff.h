@@ -99,6 +99,15 @@ double dsd_plan_flops(dsd_handle* h);
 int dsd_forward(dsd_handle* h, const float* x, const void* t, int t_is_float, int B, int C, int H, int W,
                 float* out, float* const* feats, void* stream);
 
+/* Per-kernel timing of the plan, measured with hipEvents on the stream the kernels are launched on (one
+ * pair per op; forces a stream sync per forward, so never leave it on in a throughput run).  Totals
+ * accumulate over forwards until re-enabled.  kind = kernel name, flops / bytes = the algorithmic work of
+ * those launches (2*MAC; fp32 read+write bytes for the memory-bound kernels). */
+int dsd_profile_enable(dsd_handle* h, int on);
+int dsd_profile_count(dsd_handle* h);
+int dsd_profile_get(dsd_handle* h, int idx, const char** kind, double* total_ms, double* flops, double* bytes,
+                    int64_t* calls, int* runs);
+
 /* ---- sampling loop ----------------------------------------------------------------------- */
 enum { DSD_MODE_A_DDPM = 0, DSD_MODE_A_DDIM = 1, DSD_MODE_B_DDPM = 2, DSD_MODE_B_DDIM = 3 };
 enum { DSD_PRED_EPS = 0, DSD_PRED_X0 = 1, DSD_PRED_V = 2 };
