@@ -173,10 +173,15 @@ def main():
         dk, dv = dom
         ach = dv["flops"] / (dv["ms"] / 1e3) / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        # HBM bytes per launch from the committed PMC passes of this same command (tools/pmc_summary.py;
+        # separate --pmc runs, FETCH_SIZE x2 on gfx950, KiB -> bytes): counters cannot be read live.
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get(dk, {}).get("hbm_bytes_per_launch")
+                want = dk.replace("conv_mfma<", "conv_mfma_kernel<")
+                for kname, e in json.load(open(pmc)).items():
+                    if want in kname:
+                        traffic = e.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {"bound": "mfma", "kernel": dk, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,

@@ -1,0 +1,111 @@
+"""infer_2d — counterpart of the reference's inference/inference_2d_*.py entry scripts for the native path.
+
+Reads the SAME yaml keys (model yaml: ``model.params.{unet_config, parameterization, …}``; inference yaml:
+``sampler_setting.{sampler, sample_steps, ddim_eta, ddim_use_original_steps}``, ``test_batch_size``, ``seed``,
+``cuda_idx`` — configs/inference_config_BraTs.yaml:11-19 of the reference) but takes slices as ``.npy``
+``[N,C,H,W]`` (C = 1 or 3 condition channels, already scaled to [-1,1] and resized to a multiple of 32 as the
+reference's transforms do) and writes ``[N,1,H,W]``; NIfTI/h5/MONAI I/O is out of scope.
+
+Sampler selection follows TryTrainerDiffusion.on_predict_start (trainers/trainer_use_gaussian_diff.py:586-600):
+the diffusion is rebuilt with ``timestep_respacing = str(sample_steps)`` and ``rescale_timesteps = True`` when
+sample_steps differs from the training steps, then ``ddim_sample_loop`` or ``p_sample_loop`` is called with
+``model_kwargs = dict(c_concat=[images])`` (:602-621).  Multi-GPU: torchrun, slices sharded ``[r::R]``.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
+    ap.add_argument("--model-yaml", required=True)
+    ap.add_argument("--infer-yaml", required=True)
+    ap.add_argument("--input", required=True, help=".npy [N,C,H,W] condition slices")
+    ap.add_argument("--output", required=True)
+    ap.add_argument("--ckpt", default=None, help="torch state_dict file (plain tensors; keys may carry model.diffusion_model.)")
+    ap.add_argument("--synthetic-weights", type=int, default=None, help="seed: random-init weights (no checkpoint)")
+    args = ap.parse_args(argv)
+
+    from . import parallel
+    from ._sched import run_device_loop  # noqa: F401
+    from .ldm.util import instantiate_from_config
+    from .Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    icfg = yaml.safe_load(open(args.infer_yaml))
+    mcfg = yaml.safe_load(open(args.model_yaml))
+    mp = mcfg["model"]["params"]
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dev_index = local
+    else:
+        dev_index = int(icfg.get("cuda_idx", 0)) if torch.cuda.device_count() > int(icfg.get("cuda_idx", 0)) else 0
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    rank, ws = parallel.world()
+    torch.manual_seed(int(icfg.get("seed", 2024)) + rank)
+
+    uc = dict(mp["unet_config"])
+    learn_sigma = bool(mp.get("learn_sigma", False))
+    uc["params"] = dict(uc["params"], device_index=dev_index, out_channels=2 if learn_sigma else 1)  # trainer :69
+    unet = instantiate_from_config(uc)
+    if rank == 0:
+        if args.ckpt:
+            sd = torch.load(args.ckpt, map_location="cpu", weights_only=True)
+            sd = sd.get("state_dict", sd)
+            pre = "model.diffusion_model."
+            sd = {(k[len(pre):] if k.startswith(pre) else k): v for k, v in sd.items()}
+            unet.load_state_dict({k: v for k, v in sd.items() if k in unet.state_dict()}, strict=True)
+        elif args.synthetic_weights is not None:
+            g = torch.Generator().manual_seed(args.synthetic_weights)
+            with torch.no_grad():
+                for p in unet.parameters():
+                    if float(p.abs().max()) == 0.0:
+                        p.normal_(0.0, 0.02, generator=g)
+        else:
+            raise SystemExit("give --ckpt or --synthetic-weights")
+    parallel.broadcast_packed(dict(unet.named_parameters()), 0, dev)
+
+    ss = icfg["sampler_setting"]
+    steps_train = int(mp.get("diffusion_steps", 1000))
+    sample_steps = int(ss.get("sample_steps", steps_train))
+    respace, rescale = mp.get("timestep_respacing", ""), bool(mp.get("rescale_timesteps", False))
+    if sample_steps != steps_train:
+        respace, rescale = str(sample_steps), True
+    diffusion = create_gaussian_diffusion(steps=steps_train, learn_sigma=learn_sigma,
+                                          noise_schedule=mp.get("noise_schedule", "linear"),
+                                          predict_xstart=bool(mp.get("predict_xstart", False)), rescale_timesteps=rescale,
+                                          timestep_respacing=respace, parameterization=mp.get("parameterization", "eps"))
+    sample_fn = diffusion.ddim_sample_loop if ss.get("sampler", "ddpm") == "ddim" else diffusion.p_sample_loop
+    extra = {"eta": float(ss.get("ddim_eta", 0))} if ss.get("sampler", "ddpm") == "ddim" else {}
+
+    cond_all = np.load(args.input, mmap_mode="r")
+    n = cond_all.shape[0]
+    mine = parallel.shard_indices(n, rank, ws)
+    bs = int(icfg.get("test_batch_size", 16))
+    outs = []
+    for i in range(0, len(mine), bs):
+        idx = mine[i:i + bs]
+        images = torch.from_numpy(np.ascontiguousarray(cond_all[idx])).float().to(dev)
+        B, _, H, W = images.shape
+        outs.append(sample_fn(unet, (B, 1, H, W), clip_denoised=bool(mp.get("clip_denoised", True)),
+                              model_kwargs=dict(c_concat=[images]), **extra))
+    local_out = torch.cat(outs) if outs else torch.zeros((0, 1) + tuple(cond_all.shape[2:]), device=dev)
+    full = parallel.gather_slices(local_out, n, 0)
+    if rank == 0:
+        np.save(args.output, full.cpu().numpy())
+        print(f"wrote {args.output}: {tuple(full.shape)}")
+    if ws > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
