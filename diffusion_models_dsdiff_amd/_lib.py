@@ -24,7 +24,7 @@ PRED_EPS, PRED_X0, PRED_V = 0, 1, 2
 EXPORTS = [
     "dsd_last_error", "dsd_device_info", "dsd_create", "dsd_destroy", "dsd_param_count", "dsd_param_info",
     "dsd_set_param", "dsd_set_timestep_freqs", "dsd_params_ready", "dsd_plan", "dsd_workspace_bytes", "dsd_plan_launches", "dsd_plan_flops",
-    "dsd_profile_enable", "dsd_profile_count", "dsd_profile_get", "dsd_forward", "dsd_sample", "dsd_op_sampler_update", "dsd_block_create", "dsd_block_forward", "dsd_op_conv2d",
+    "dsd_profile_enable", "dsd_profile_count", "dsd_profile_get", "dsd_forward", "dsd_sample", "dsd_op_sampler_update", "dsd_block_create", "dsd_block_forward", "dsd_bench_conv2d", "dsd_op_conv2d",
     "dsd_op_group_norm", "dsd_op_qkv_attention", "dsd_op_timestep_embedding", "dsd_op_linear", "dsd_op_philox_normal",
 ]
 
@@ -103,6 +103,7 @@ def lib() -> C.CDLL:
     L.dsd_block_create.argtypes = [i32, C.POINTER(C.c_int32), i32, i32, C.POINTER(vp)]
     L.dsd_block_forward.argtypes = [vp, f32p, i32, i32, i32, i32, f32p, i32, f32p, i32, f32p, vp]
     L.dsd_op_conv2d.argtypes = [f32p, i32, i32, i32, i32, f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, vp]
+    L.dsd_bench_conv2d.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_double)]
     L.dsd_op_group_norm.argtypes = [f32p, i32, i32, i32, f32p, f32p, C.c_float, i32, f32p, vp]
     L.dsd_op_qkv_attention.argtypes = [f32p, i32, i32, i32, i32, i32, f32p, vp]
     L.dsd_op_timestep_embedding.argtypes = [vp, i32, i32, i32, f32p, vp]

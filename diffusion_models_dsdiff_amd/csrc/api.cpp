@@ -336,6 +336,38 @@ int dsd_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w_o
     DSD_CATCH
 }
 
+int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride, int variant, int iters, float* avg_ms,
+                     double* flops) {
+    DSD_TRY
+    DSD_CHECK(iters >= 1 && avg_ms, "bad argument");
+    hipStream_t s = nullptr;
+    const int pad = ks / 2;
+    const int OH = (H + 2 * pad - ks) / stride + 1, OW = (W + 2 * pad - ks) / stride + 1;
+    const size_t nx = (size_t)N * H * W * Cin, nw = (size_t)Cout * Cin * ks * ks, ny = (size_t)N * OH * OW * Cout;
+    Tmp x(nx * 4), w(nw * 4), b((size_t)Cout * 4), y(ny * 4);
+    philox_normal(x.as<float>(), (int64_t)nx, 1, 0, s);
+    philox_normal(w.as<float>(), (int64_t)nw, 2, 0, s);
+    philox_normal(b.as<float>(), Cout, 3, 0, s);
+    ConvArgs a;
+    a.x = x.as<float>(); a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.w = w.as<float>(); a.bias = b.as<float>();
+    a.Cout = Cout; a.ks = ks; a.stride = stride; a.y = y.as<float>(); a.variant = variant;
+    conv2d(a, s);  // warm-up
+    hipEvent_t e0, e1;
+    DSD_HIP(hipEventCreate(&e0));
+    DSD_HIP(hipEventCreate(&e1));
+    DSD_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) conv2d(a, s);
+    DSD_HIP(hipEventRecord(e1, s));
+    DSD_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    DSD_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    if (flops) *flops = conv2d_flops(a);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    DSD_CATCH
+}
+
 int dsd_op_group_norm(const float* x, int N, int HW, int C, const float* gamma, const float* beta, float eps, int silu,
                       float* y, void* stream) {
     DSD_TRY

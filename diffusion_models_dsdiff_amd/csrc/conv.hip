@@ -17,6 +17,8 @@
 //   Epilogue fuses bias, the per-(sample,channel) timestep-embedding add and the residual add.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace dsd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -35,9 +37,139 @@ struct ConvP {
     int64_t x_bs;
     int N, H, W, Cin, Cout, OH, OW, ks, stride, pad, ups, emb_stride, out_nchw;
     int M, Ktot, cchunks, IHg, IWg, tiles_m, tiles_n, ohw;
+    unsigned x_bytes, w_bytes;  // buffer-descriptor extents (buffer-load kernel only)
+    int diag;  // timing diagnostics only (wrong results): 1 = every block gathers the SAME A rows (L2-hot)
 };
 
+
+// ---- accumulator tile -> memory.  C/D map of a 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+// Interior tiles (the common case) take a branch-free path: bias once per column, then per group of 4 rows all
+// residual / embedding loads are issued together before the adds and stores (one vmcnt wait per group instead of
+// one dependent global load per element).
 template <int NT>
+__device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x16 (&acc)[NT], int m0, int n0, int wave, int lrow,
+                                              int half) {
+    const bool interior = (m0 + BM <= p.M) && (n0 + NT * 32 <= p.Cout) && !p.out_nchw;
+    if (interior) {
+        float bj[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bj[j] = p.bias ? p.bias[n0 + j * 32 + lrow] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int mb = m0 + wave * 32 + 8 * g + 4 * half;  // rows mb .. mb+3  <->  regs 4g .. 4g+3
+            float ev[4][NT], rv[4][NT];
+            if (p.emb) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float* er = p.emb + (int64_t)((mb + rr) / p.ohw) * p.emb_stride + n0 + lrow;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) ev[rr][j] = er[j * 32];
+                }
+            }
+            if (p.res) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float* rp = p.res + (int64_t)(mb + rr) * p.Cout + n0 + lrow;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) rv[rr][j] = rp[j * 32];
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float* yp = p.y + (int64_t)(mb + rr) * p.Cout + n0 + lrow;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    float v = acc[j][4 * g + rr] + bj[j];
+                    if (p.emb) v += ev[rr][j];
+                    if (p.res) v += rv[rr][j];
+                    yp[j * 32] = v;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= p.M) continue;
+        const int nb = m / p.ohw;
+        const float* embrow = p.emb ? p.emb + (int64_t)nb * p.emb_stride : nullptr;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 32 + lrow;
+            if (n >= p.Cout) continue;
+            float v = acc[j][r];
+            if (p.bias) v += p.bias[n];
+            if (embrow) v += embrow[n];
+            if (p.res) v += p.res[(int64_t)m * p.Cout + n];
+            if (p.out_nchw) {
+                const int pix = m - nb * p.ohw;
+                p.y[((int64_t)nb * p.Cout + n) * p.ohw + pix] = v;
+            } else {
+                p.y[(int64_t)m * p.Cout + n] = v;
+            }
+        }
+    }
+}
+
+// ---- MFMAs of NKG k-groups (8 k each) of one staged tile, fragment reads software-pipelined ONE group ahead:
+// the ds_read_b128 of group g+1 is issued before the four MFMAs of group g, so its latency hides behind 256 cycles
+// of matrix work instead of being waited for in front of every group.
+template <int NT, int NKG, int LSTRIDE>
+__device__ __forceinline__ void conv_tile_mfma(const float* a_frag, const float* b_frag, f32x16 (&acc)[NT]) {
+    float4 a_cur = *reinterpret_cast<const float4*>(a_frag);
+    float4 b_cur = *reinterpret_cast<const float4*>(b_frag);
+    float4 a_nxt = a_cur, b_nxt = b_cur;
+#pragma unroll
+    for (int kg = 0; kg < NKG; ++kg) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j + 1 < NT) {
+                b_nxt = *reinterpret_cast<const float4*>(b_frag + (j + 1) * 32 * LSTRIDE + 8 * kg);
+            } else if (kg + 1 < NKG) {
+                b_nxt = *reinterpret_cast<const float4*>(b_frag + 8 * (kg + 1));
+                a_nxt = *reinterpret_cast<const float4*>(a_frag + 8 * (kg + 1));
+            }
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur.x, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur.y, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur.z, acc[j], 0, 0, 0);
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur.w, acc[j], 0, 0, 0);
+            b_cur = b_nxt;
+            if (j == NT - 1) a_cur = a_nxt;
+        }
+    }
+}
+
+// Same work, MFMA order interleaved over the NT accumulators (each accumulator is touched every NT-th MFMA instead
+// of four times in a row): all NT+1 fragments of a k-group are read one group ahead.
+template <int NT, int NKG, int LSTRIDE>
+__device__ __forceinline__ void conv_tile_mfma_ilv(const float* a_frag, const float* b_frag, f32x16 (&acc)[NT]) {
+    float4 a_cur = *reinterpret_cast<const float4*>(a_frag), a_nxt = a_cur;
+    float4 b_cur[NT], b_nxt[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) b_nxt[j] = b_cur[j] = *reinterpret_cast<const float4*>(b_frag + j * 32 * LSTRIDE);
+#pragma unroll
+    for (int kg = 0; kg < NKG; ++kg) {
+        if (kg + 1 < NKG) {
+            a_nxt = *reinterpret_cast<const float4*>(a_frag + 8 * (kg + 1));
+#pragma unroll
+            for (int j = 0; j < NT; ++j) b_nxt[j] = *reinterpret_cast<const float4*>(b_frag + j * 32 * LSTRIDE + 8 * (kg + 1));
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur[j].x, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur[j].y, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur[j].z, acc[j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur[j].w, acc[j], 0, 0, 0);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) b_cur[j] = b_nxt[j];
+    }
+}
+
+template <int NT, bool ILV = false>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
     __shared__ __attribute__((aligned(16))) float lds[(BM + NT * 32) * LDS_STRIDE];
     float* As = lds;
@@ -70,6 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
         int m = m0 + srow + 32 * i;
         a_ok[i] = m < p.M;
         m = a_ok[i] ? m : 0;
+        if (p.diag == 1) m = srow + 32 * i;
         const int n = m / p.ohw;
         const int r = m - n * p.ohw;
         const int oh = r / p.OW;
@@ -127,13 +260,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
     int kh = 0, kw = 0, cc = 0;
     load_tile(kh, kw, cc);
     for (int kt = 0; kt < KT; ++kt) {
-        __syncthreads();  // all waves finished reading the previous tile
+        if (p.diag != 3) {
+            __syncthreads();  // all waves finished reading the previous tile
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(a_st + 32 * i * LDS_STRIDE) = ra[i];
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(a_st + 32 * i * LDS_STRIDE) = ra[i];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(b_st + 32 * j * LDS_STRIDE) = rb[j];
-        __syncthreads();
-        if (kt + 1 < KT) {  // prefetch next tile into registers; lands while the MFMAs below run
+            for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(b_st + 32 * j * LDS_STRIDE) = rb[j];
+            __syncthreads();
+        }
+        if (kt + 1 < KT && p.diag < 2) {  // prefetch next tile into registers; lands while the MFMAs below run
             if (++cc == p.cchunks) {
                 cc = 0;
                 if (++kw == p.ks) {
@@ -143,43 +278,267 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
             }
             load_tile(kh, kw, cc);
         }
-#pragma unroll
-        for (int kg = 0; kg < 4; ++kg) {
-            const float4 a4 = *reinterpret_cast<const float4*>(a_frag + 8 * kg);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float4 b4 = *reinterpret_cast<const float4*>(b_frag + j * 32 * LDS_STRIDE + 8 * kg);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc[j], 0, 0, 0);
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc[j], 0, 0, 0);
-            }
-        }
+        if (ILV)
+            conv_tile_mfma_ilv<NT, 4, LDS_STRIDE>(a_frag, b_frag, acc);
+        else
+            conv_tile_mfma<NT, 4, LDS_STRIDE>(a_frag, b_frag, acc);
     }
 
-    // ---- epilogue: C/D map of the 32x32 tile: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    conv_epilogue<NT>(p, acc, m0, n0, wave, lrow, half);
+}
+
+// Default kernel: same tiling/loop as conv_mfma_kernel, but the operand gathers use BUFFER loads: a 32-bit per-lane
+// byte offset that is recomputed only when the filter tap changes (every Cin/32 tiles), a scalar per-tile offset, and
+// the hardware range check instead of exec-masked branches for padding / ragged rows (an out-of-range offset returns
+// zeros).  The flat-load kernel spends ~12 % of its time issuing address arithmetic and branches (tools/bench_conv.py
+// diagnostics); this one issues 9 loads and two scalar adds per tile.  Needs Cin % 32 == 0 and < 4 GiB operands.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+static constexpr unsigned OOB = 0xFFFFFFF0u;
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_mfma_buf_kernel(ConvP p) {
+    __shared__ __attribute__((aligned(16))) float lds[(BM + NT * 32) * LDS_STRIDE];
+    float* As = lds;
+    float* Bs = lds + BM * LDS_STRIDE;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwg = gridDim.x;
+    int L = blockIdx.x;
+    {
+        const int cpx = nwg >> 3;
+        if (L < (cpx << 3)) L = (L & 7) * cpx + (L >> 3);
+    }
+    const int tile_n = L % p.tiles_n;
+    const int tile_m = L / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * (NT * 32);
+
+    const int col4 = tid & 7;
+    const int srow = tid >> 3;
+    int a_h[4], a_w[4];
+    unsigned a_nb[4];
+    bool a_ok[4];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m >= p.M) continue;
-        const int nb = m / p.ohw;
-        const float* embrow = p.emb ? p.emb + (int64_t)nb * p.emb_stride : nullptr;
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + srow + 32 * i;
+        a_ok[i] = m < p.M;
+        m = a_ok[i] ? m : 0;
+        const int n = m / p.ohw;
+        const int r = m - n * p.ohw;
+        const int oh = r / p.OW;
+        const int ow = r - oh * p.OW;
+        a_h[i] = oh * p.stride - p.pad;
+        a_w[i] = ow * p.stride - p.pad;
+        a_nb[i] = (unsigned)n * (unsigned)p.x_bs + (unsigned)(col4 * 4);
+    }
+    unsigned b_voff[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + j * 32 + lrow;
-            if (n >= p.Cout) continue;
-            float v = acc[j][r];
-            if (p.bias) v += p.bias[n];
-            if (embrow) v += embrow[n];
-            if (p.res) v += p.res[(int64_t)m * p.Cout + n];
-            if (p.out_nchw) {
-                const int pix = m - nb * p.ohw;
-                p.y[((int64_t)nb * p.Cout + n) * p.ohw + pix] = v;
-            } else {
-                p.y[(int64_t)m * p.Cout + n] = v;
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + srow + 32 * j;
+        b_voff[j] = n < p.Cout ? ((unsigned)n * (unsigned)p.Ktot + (unsigned)(col4 * 4)) * 4u : OOB;
+    }
+    unsigned a_voff[4];
+    auto tap_offsets = [&](int kh, int kw) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ih = a_h[i] + kh, iw = a_w[i] + kw;
+            const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.IHg && (unsigned)iw < (unsigned)p.IWg;
+            if (p.ups) {
+                ih >>= 1;
+                iw >>= 1;
+            }
+            a_voff[i] = ok ? (a_nb[i] + (unsigned)(ih * p.W + iw) * (unsigned)p.Cin) * 4u : OOB;
+        }
+    };
+    f32x4 ra[4], rb[NT];
+    auto load_tile = [&](int soff_a, int soff_b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[i], soff_a, 0));
+#pragma unroll
+        for (int j = 0; j < NT; ++j) rb[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[j], soff_b, 0));
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int lrow = lane & 31;
+    const int half = lane >> 5;
+    const float* a_frag = As + (wave * 32 + lrow) * LDS_STRIDE + 4 * half;
+    const float* b_frag = Bs + lrow * LDS_STRIDE + 4 * half;
+    float* a_st = As + srow * LDS_STRIDE + col4 * 4;
+    float* b_st = Bs + srow * LDS_STRIDE + col4 * 4;
+
+    const int KT = p.ks * p.ks * p.cchunks;
+    int kh = 0, kw = 0, cc = 0, tap = 0;
+    tap_offsets(0, 0);
+    load_tile(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(a_st + 32 * i * LDS_STRIDE) = ra[i];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<f32x4*>(b_st + 32 * j * LDS_STRIDE) = rb[j];
+        __syncthreads();
+        if (kt + 1 < KT) {
+            if (++cc == p.cchunks) {
+                cc = 0;
+                ++tap;
+                if (++kw == p.ks) {
+                    kw = 0;
+                    ++kh;
+                }
+                tap_offsets(kh, kw);
+            }
+            load_tile(cc * (BK * 4), (tap * p.Cin + cc * BK) * 4);
+        }
+        conv_tile_mfma<NT, 4, LDS_STRIDE>(a_frag, b_frag, acc);
+    }
+    conv_epilogue<NT>(p, acc, m0, n0, wave, lrow, half);
+}
+
+// Variant "db16": same tile (128 x 32*NT) but BK = 16 with TWO LDS buffers and ONE barrier per K tile: the
+// staged registers of tile kt+1 are written to the other buffer in the middle of tile kt's MFMAs and the global
+// loads of tile kt+2 are issued right after, so neither the LDS write phase nor the load issue is exposed.
+// LDS 2 x (128+32*NT) x 20 floats (46 KB at NT=5) -> 3 workgroups per CU.
+static constexpr int BK2 = 16;
+static constexpr int LS2 = 20;
+
+template <int NT>
+__global__ __launch_bounds__(256, 3) void conv_mfma_db16_kernel(ConvP p) {
+    constexpr int ROWS = BM + NT * 32;
+    constexpr int BJ = (NT * 32 + 63) / 64;  // B staging passes of 64 rows
+    __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * LS2];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwg = gridDim.x;
+    int L = blockIdx.x;
+    {
+        const int cpx = nwg >> 3;
+        if (L < (cpx << 3)) L = (L & 7) * cpx + (L >> 3);
+    }
+    const int tile_n = L % p.tiles_n;
+    const int tile_m = L / p.tiles_n;
+    const int m0 = tile_m * BM;
+    const int n0 = tile_n * (NT * 32);
+
+    // staging map: thread -> (row = tid>>2 (+64 i), 4 consecutive k = 4*(tid&3))
+    const int col4 = tid & 3;
+    const int srow = tid >> 2;
+    int a_h[2], a_w[2];
+    int64_t a_nb[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + srow + 64 * i;
+        a_ok[i] = m < p.M;
+        m = a_ok[i] ? m : 0;
+        const int n = m / p.ohw;
+        const int r = m - n * p.ohw;
+        const int oh = r / p.OW;
+        const int ow = r - oh * p.OW;
+        a_h[i] = oh * p.stride - p.pad;
+        a_w[i] = ow * p.stride - p.pad;
+        a_nb[i] = (int64_t)n * p.x_bs;
+    }
+    const float* wrow[BJ];
+    bool b_ok[BJ];
+#pragma unroll
+    for (int j = 0; j < BJ; ++j) {
+        const int rr = srow + 64 * j;
+        const int n = n0 + rr;
+        b_ok[j] = rr < NT * 32 && n < p.Cout;
+        wrow[j] = p.w + (int64_t)(b_ok[j] ? n : 0) * p.Ktot;
+    }
+    const int cch = (p.Cin + BK2 - 1) / BK2;  // K chunks of 16 per tap
+
+    float4 ra[2], rb[BJ];
+    auto load_tile = [&](int kh, int kw, int cc) {
+        const int c = cc * BK2 + col4 * 4;
+        const bool cok = c < p.Cin;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int ih = a_h[i] + kh, iw = a_w[i] + kw;
+            const bool ok = a_ok[i] && cok && (unsigned)ih < (unsigned)p.IHg && (unsigned)iw < (unsigned)p.IWg;
+            if (p.ups) {
+                ih >>= 1;
+                iw >>= 1;
+            }
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) ra[i] = *reinterpret_cast<const float4*>(p.x + a_nb[i] + ((int64_t)ih * p.W + iw) * p.Cin + c);
+        }
+        const int kofs = (kh * p.ks + kw) * p.Cin + c;
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) {
+            rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b_ok[j] && cok) rb[j] = *reinterpret_cast<const float4*>(wrow[j] + kofs);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        float* base = lds + buf * (ROWS * LS2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(base + (srow + 64 * i) * LS2 + col4 * 4) = ra[i];
+#pragma unroll
+        for (int j = 0; j < BJ; ++j)
+            if (srow + 64 * j < NT * 32) *reinterpret_cast<float4*>(base + (BM + srow + 64 * j) * LS2 + col4 * 4) = rb[j];
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int lrow = lane & 31;
+    const int half = lane >> 5;
+    const int a_off = (wave * 32 + lrow) * LS2 + 4 * half;
+    const int b_off = (BM + lrow) * LS2 + 4 * half;
+
+    auto compute = [&](int buf, int kg) {
+        const float* base = lds + buf * (ROWS * LS2);
+        conv_tile_mfma<NT, 1, LS2>(base + a_off + 8 * kg, base + b_off + 8 * kg, acc);
+    };
+    auto advance = [&](int& kh, int& kw, int& cc) {
+        if (++cc == cch) {
+            cc = 0;
+            if (++kw == p.ks) {
+                kw = 0;
+                ++kh;
             }
         }
+    };
+
+    const int KT = p.ks * p.ks * cch;
+    int kh = 0, kw = 0, cc = 0;
+    load_tile(kh, kw, cc);
+    store_tile(0);
+    if (KT > 1) {
+        advance(kh, kw, cc);
+        load_tile(kh, kw, cc);
     }
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int cur = kt & 1;
+        compute(cur, 0);
+        if (kt + 1 < KT) store_tile(cur ^ 1);   // tile kt+1 (its global loads were issued one tile ago)
+        if (kt + 2 < KT) {
+            advance(kh, kw, cc);
+            load_tile(kh, kw, cc);              // tile kt+2, lands during the next tile's MFMAs
+        }
+        compute(cur, 1);
+        __syncthreads();
+    }
+
+    conv_epilogue<NT>(p, acc, m0, n0, wave, lrow, half);
 }
 
 // Direct kernel for tiny K (first layer: Cin = 1, K = 9): output-write bound, weights staged in LDS as [k][Cout].
@@ -296,6 +655,16 @@ double conv2d_flops(const ConvArgs& a) {
     return 2.0 * a.N * OH * OW * (double)a.Cout * a.ks * a.ks * a.Cin;
 }
 
+// kernel variant: ConvArgs.variant >= 0 wins, else env DSD_CONV_VARIANT, else the default
+static int conv_variant(const ConvArgs& a) {
+    if (a.variant >= 0) return a.variant;
+    static const int env = [] {
+        const char* e = getenv("DSD_CONV_VARIANT");
+        return e ? atoi(e) : 0;
+    }();
+    return env;
+}
+
 static int pick_nt(int Cout, int tiles_m) {
     const int t32 = cdiv(Cout, 32);
     int best = 1, best_waste = 1 << 30;
@@ -360,6 +729,48 @@ void conv2d(ConvArgs a, hipStream_t s) {
     const int nt = pick_nt(a.Cout, p.tiles_m);
     p.tiles_n = cdiv(a.Cout, nt * 32);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    if (conv_variant(a) == 1) {
+        switch (nt) {
+            case 1: hipLaunchKernelGGL(conv_mfma_db16_kernel<1>, grid, dim3(256), 0, s, p); break;
+            case 2: hipLaunchKernelGGL(conv_mfma_db16_kernel<2>, grid, dim3(256), 0, s, p); break;
+            case 3: hipLaunchKernelGGL(conv_mfma_db16_kernel<3>, grid, dim3(256), 0, s, p); break;
+            case 4: hipLaunchKernelGGL(conv_mfma_db16_kernel<4>, grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL(conv_mfma_db16_kernel<5>, grid, dim3(256), 0, s, p); break;
+        }
+        check_launch("conv_mfma_db16");
+        return;
+    }
+    if (conv_variant(a) >= 3 && conv_variant(a) <= 5) p.diag = conv_variant(a) - 2;  // 3,4,5 -> diag 1,2,3 (timing diagnostics)
+    {
+        // default path: buffer-load kernel when the operands are addressable with 32-bit byte offsets
+        const int64_t xb = ((int64_t)(a.N - 1) * p.x_bs + (int64_t)a.H * a.W * a.Cin) * 4;
+        const int64_t wb = (int64_t)a.Cout * p.Ktot * 4;
+        const bool buf_ok = a.Cin % BK == 0 && xb < 0xFFFFFF00ll && wb < 0xFFFFFF00ll && p.x_bs >= 0;
+        if (buf_ok && (conv_variant(a) == 0)) {
+            p.x_bytes = (unsigned)xb;
+            p.w_bytes = (unsigned)wb;
+            switch (nt) {
+                case 1: hipLaunchKernelGGL(conv_mfma_buf_kernel<1>, grid, dim3(256), 0, s, p); break;
+                case 2: hipLaunchKernelGGL(conv_mfma_buf_kernel<2>, grid, dim3(256), 0, s, p); break;
+                case 3: hipLaunchKernelGGL(conv_mfma_buf_kernel<3>, grid, dim3(256), 0, s, p); break;
+                case 4: hipLaunchKernelGGL(conv_mfma_buf_kernel<4>, grid, dim3(256), 0, s, p); break;
+                default: hipLaunchKernelGGL(conv_mfma_buf_kernel<5>, grid, dim3(256), 0, s, p); break;
+            }
+            check_launch("conv_mfma_buf");
+            return;
+        }
+    }
+    if (conv_variant(a) == 2) {
+        switch (nt) {
+            case 1: hipLaunchKernelGGL((conv_mfma_kernel<1, true>), grid, dim3(256), 0, s, p); break;
+            case 2: hipLaunchKernelGGL((conv_mfma_kernel<2, true>), grid, dim3(256), 0, s, p); break;
+            case 3: hipLaunchKernelGGL((conv_mfma_kernel<3, true>), grid, dim3(256), 0, s, p); break;
+            case 4: hipLaunchKernelGGL((conv_mfma_kernel<4, true>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((conv_mfma_kernel<5, true>), grid, dim3(256), 0, s, p); break;
+        }
+        check_launch("conv_mfma_ilv");
+        return;
+    }
     switch (nt) {
         case 1: hipLaunchKernelGGL(conv_mfma_kernel<1>, grid, dim3(256), 0, s, p); break;
         case 2: hipLaunchKernelGGL(conv_mfma_kernel<2>, grid, dim3(256), 0, s, p); break;

@@ -20,6 +20,7 @@ struct ConvArgs {
     float* y = nullptr;
     int out_nchw = 0;           // store as [N,Cout,OH,OW] (final layer with out_channels > 1)
     int OH = 0, OW = 0;         // filled by conv2d()
+    int variant = -1;           // kernel variant override (-1 = default / env DSD_CONV_VARIANT)
 };
 void conv2d(ConvArgs a, hipStream_t s);
 double conv2d_flops(const ConvArgs& a);

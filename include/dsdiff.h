@@ -168,6 +168,10 @@ int dsd_block_forward(dsd_handle* h, const float* x, int B, int C, int H, int W,
  * upsample=1 folds a nearest x2 in front of the conv (Upsample, openaimodel.py:111-121). */
 int dsd_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
                   int ks, int stride, int upsample, const float* emb, const float* res, float* y, void* stream);
+/* Micro-benchmark of the convolution kernel on random data (library-owned buffers): average ms per launch over
+ * `iters` back-to-back launches (hipEvents) and the algorithmic FLOPs of one launch.  variant: -1 default. */
+int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride, int variant, int iters, float* avg_ms,
+                     double* flops);
 /* GroupNorm(32, C, eps) [+ SiLU] on x[N,HW,C]. */
 int dsd_op_group_norm(const float* x, int N, int HW, int C, const float* gamma, const float* beta, float eps,
                       int silu, float* y, void* stream);
