@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel hipEvent pass")
     ap.add_argument("--model-channels", type=int, default=None, help="override (debug only; invalidates the metric)")
+    ap.add_argument("--precision", default=os.environ.get("DSD_PRECISION", "f32"), choices=["f32", "bf16x6", "bf16x3"],
+                    help="arithmetic of the convolutions (include/dsdiff.h: dsd_set_precision)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -106,6 +108,7 @@ def main():
     torch.manual_seed(2024)
     t0 = time.time()
     model = instantiate_from_config(uc)
+    model.set_precision(args.precision)
     synth_weights_(model, 2024)
     n_params = sum(p.numel() for p in model.parameters())
     # one-off weight distribution: rank 0's parameters broadcast as ONE packed blob over RCCL/xGMI

@@ -74,6 +74,17 @@ class NativeModule(nn.Module):
                 mod = mod._modules[part]
             mod.register_parameter(parts[-1], p)
 
+    def set_precision(self, precision: str):
+        """Arithmetic of the convolutions: "f32" (fp32 MFMA), "bf16x6" (fp32-grade split-bf16), "bf16x3" (see dsdiff.h).
+        The environment variable DSD_PRECISION sets the default of new modules."""
+        check(lib().dsd_set_precision(self._h, _lib.PRECISIONS[precision]))
+        return self
+
+    @property
+    def precision(self) -> str:
+        code = lib().dsd_get_precision(self._h)
+        return {v: k for k, v in _lib.PRECISIONS.items()}[code]
+
     def sync_params(self, force: bool = False):
         """Upload parameters that changed since the last upload (load_state_dict, .to(), in-place edits)."""
         L = lib()
@@ -187,6 +198,9 @@ class DSUnetModel(NativeModule):
         cfg.legacy = int(bool(legacy))
         self._cfg = cfg
         check(lib().dsd_create(C.byref(cfg), device_index, C.byref(self._h)))
+        import os
+        if os.environ.get("DSD_PRECISION"):
+            self.set_precision(os.environ["DSD_PRECISION"])
         self._build_params()
         # timestep_embedding's frequency table exactly as the reference evaluates it (util.py:172-174, torch CPU fp32 exp)
         half = model_channels // 2

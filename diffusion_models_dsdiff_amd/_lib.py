@@ -17,14 +17,15 @@ DSD_MAX_LEVELS = 8
 DSD_NCOEF = 8
 MODE_A_DDPM, MODE_A_DDIM, MODE_B_DDPM, MODE_B_DDIM = 0, 1, 2, 3
 PRED_EPS, PRED_X0, PRED_V = 0, 1, 2
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
 (BLOCK_RES, BLOCK_ATTN, BLOCK_UPSAMPLE, BLOCK_DOWNSAMPLE, BLOCK_DISENTANGLE, BLOCK_SE, BLOCK_CROSSATTN,
  BLOCK_FF_GEGLU, BLOCK_BASIC_TRANSFORMER, BLOCK_SPATIAL_TRANSFORMER) = range(10)
 
 # every symbol include/dsdiff.h declares (tests/test_abi.py checks the header against this list)
 EXPORTS = [
     "dsd_last_error", "dsd_device_info", "dsd_create", "dsd_destroy", "dsd_param_count", "dsd_param_info",
-    "dsd_set_param", "dsd_set_timestep_freqs", "dsd_params_ready", "dsd_plan", "dsd_workspace_bytes", "dsd_plan_launches", "dsd_plan_flops",
-    "dsd_profile_enable", "dsd_profile_count", "dsd_profile_get", "dsd_forward", "dsd_sample", "dsd_op_sampler_update", "dsd_block_create", "dsd_block_forward", "dsd_bench_conv2d", "dsd_op_conv2d",
+    "dsd_set_param", "dsd_set_timestep_freqs", "dsd_set_precision", "dsd_get_precision", "dsd_params_ready", "dsd_plan", "dsd_workspace_bytes", "dsd_plan_launches", "dsd_plan_flops",
+    "dsd_profile_enable", "dsd_profile_count", "dsd_profile_get", "dsd_forward", "dsd_sample", "dsd_op_sampler_update", "dsd_block_create", "dsd_block_forward", "dsd_bench_conv2d", "dsd_op_conv2d", "dsd_op_conv2d_prec",
     "dsd_op_group_norm", "dsd_op_qkv_attention", "dsd_op_timestep_embedding", "dsd_op_linear", "dsd_op_philox_normal",
 ]
 
@@ -86,6 +87,8 @@ def lib() -> C.CDLL:
     L.dsd_param_info.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     L.dsd_set_param.argtypes = [vp, C.c_char_p, f32p, C.POINTER(C.c_int64), i32, i32, vp]
     L.dsd_set_timestep_freqs.argtypes = [vp, f32p, i32]
+    L.dsd_set_precision.argtypes = [vp, i32]
+    L.dsd_get_precision.argtypes = [vp]
     L.dsd_params_ready.argtypes = [vp]
     L.dsd_plan.argtypes = [vp, i32, i32, i32, i32]
     L.dsd_workspace_bytes.argtypes = [vp]
@@ -104,6 +107,7 @@ def lib() -> C.CDLL:
     L.dsd_block_forward.argtypes = [vp, f32p, i32, i32, i32, i32, f32p, i32, f32p, i32, f32p, vp]
     L.dsd_op_conv2d.argtypes = [f32p, i32, i32, i32, i32, f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, vp]
     L.dsd_bench_conv2d.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), C.POINTER(C.c_double)]
+    L.dsd_op_conv2d_prec.argtypes = [f32p, i32, i32, i32, i32, f32p, f32p, i32, i32, i32, i32, f32p, f32p, i32, f32p, vp]
     L.dsd_op_group_norm.argtypes = [f32p, i32, i32, i32, f32p, f32p, C.c_float, i32, f32p, vp]
     L.dsd_op_qkv_attention.argtypes = [f32p, i32, i32, i32, i32, i32, f32p, vp]
     L.dsd_op_timestep_embedding.argtypes = [vp, i32, i32, i32, f32p, vp]

@@ -24,6 +24,9 @@ class _Block(NativeModule):
         _lib.require_gpu(device_index)
         arr = (C.c_int32 * len(iargs))(*[int(v) for v in iargs])
         check(lib().dsd_block_create(kind, arr, len(iargs), device_index, C.byref(self._h)))
+        import os
+        if os.environ.get("DSD_PRECISION"):
+            self.set_precision(os.environ["DSD_PRECISION"])
         self._build_params()
 
     def _out_shape(self, x):

@@ -175,6 +175,19 @@ int dsd_set_timestep_freqs(dsd_handle* h, const float* freqs_host, int n) {
     DSD_CATCH
 }
 
+int dsd_set_precision(dsd_handle* h, int precision) {
+    DSD_TRY
+    DSD_CHECK(h, "null handle");
+    DSD_CHECK(precision >= PREC_F32 && precision <= PREC_BF16X6, "unknown precision %d", precision);
+    if (h->precision != precision) {
+        h->precision = precision;
+        h->plan.valid = false;   // the plan bakes the kernel choice in
+    }
+    DSD_CATCH
+}
+
+int dsd_get_precision(dsd_handle* h) { return h ? h->precision : -1; }
+
 int dsd_params_ready(dsd_handle* h) {
     DSD_TRY
     DSD_CHECK(h, "null handle");
@@ -350,7 +363,13 @@ int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride,
     philox_normal(b.as<float>(), Cout, 3, 0, s);
     ConvArgs a;
     a.x = x.as<float>(); a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.w = w.as<float>(); a.bias = b.as<float>();
-    a.Cout = Cout; a.ks = ks; a.stride = stride; a.y = y.as<float>(); a.variant = variant;
+    a.Cout = Cout; a.ks = ks; a.stride = stride; a.y = y.as<float>(); a.variant = variant >= 10 ? -1 : variant;
+    Tmp planes(nw * 2 * 3);
+    if (variant >= 10) {  // 10 = bf16x3, 11 = bf16x6
+        split_weights(w.as<float>(), (int64_t)nw, 3, planes.p, s);
+        a.w_split = planes.p;
+        a.precision = variant == 10 ? PREC_BF16X3 : PREC_BF16X6;
+    }
     conv2d(a, s);  // warm-up
     hipEvent_t e0, e1;
     DSD_HIP(hipEventCreate(&e0));
@@ -365,6 +384,26 @@ int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride,
     if (flops) *flops = conv2d_flops(a);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    DSD_CATCH
+}
+
+int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout, int ks,
+                       int stride, int upsample, const float* emb, const float* res, int precision, float* y, void* stream) {
+    DSD_TRY
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nw = (size_t)Cout * Cin * ks * ks;
+    Tmp wp(nw * sizeof(float)), planes(nw * 2 * 3);
+    pack_ohwi(w_oihw, wp.as<float>(), Cout, Cin, ks, s);
+    ConvArgs a;
+    a.x = x; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.w = wp.as<float>(); a.bias = bias; a.Cout = Cout; a.ks = ks;
+    a.stride = stride; a.ups = upsample; a.emb = emb; a.emb_stride = Cout; a.res = res; a.y = y;
+    if (precision != PREC_F32) {
+        split_weights(wp.as<float>(), (int64_t)nw, 3, planes.p, s);
+        a.w_split = planes.p;
+        a.precision = precision;
+    }
+    conv2d(a, s);
+    DSD_HIP(hipStreamSynchronize(s));
     DSD_CATCH
 }
 

@@ -13,8 +13,15 @@
 //   K order inside a group of 8 is permuted (lane half h takes k = 8g+4h+j for MFMA j) identically for A
 //   and B, so one 16-byte LDS read feeds four MFMAs.
 //   Global -> register prefetch of tile kt+1 is issued before the MFMAs of tile kt (single LDS buffer,
-//   2-3 blocks per CU hide the barriers).
-//   Epilogue fuses bias, the per-(sample,channel) timestep-embedding add and the residual add.
+//   2 blocks per CU hide the barriers).  Epilogue fuses bias, the per-(sample,channel) timestep-embedding
+//   add and the residual add.
+//   Two kernels share the tile code: conv_mfma_buf_kernel (default; buffer loads, hardware range check for
+//   padding) and conv_mfma_kernel (flat loads + masks; any Cin % 4 == 0, operands >= 4 GiB).
+//   Measured on the way here (tools/bench_conv.py, 16x256x256x320->320): flat loads 125 TF/s; + fragment
+//   reads issued one group ahead and a branch-free epilogue 129; MFMA + LDS reads alone 151, + barriers and
+//   LDS writes 147, i.e. the flat kernel lost 12 % to address arithmetic / branches in the load phase;
+//   buffer loads 143 (91 % of the 157.3 TF/s fp32 matrix peak).  A double-buffered BK=16 / one-barrier
+//   variant and an accumulator-interleaved MFMA order were tried and are not faster (142 / 127).
 #include "kernels.h"
 
 #include <cstdlib>
@@ -38,7 +45,6 @@ struct ConvP {
     int N, H, W, Cin, Cout, OH, OW, ks, stride, pad, ups, emb_stride, out_nchw;
     int M, Ktot, cchunks, IHg, IWg, tiles_m, tiles_n, ohw;
     unsigned x_bytes, w_bytes;  // buffer-descriptor extents (buffer-load kernel only)
-    int diag;  // timing diagnostics only (wrong results): 1 = every block gathers the SAME A rows (L2-hot)
 };
 
 
@@ -140,36 +146,7 @@ __device__ __forceinline__ void conv_tile_mfma(const float* a_frag, const float*
     }
 }
 
-// Same work, MFMA order interleaved over the NT accumulators (each accumulator is touched every NT-th MFMA instead
-// of four times in a row): all NT+1 fragments of a k-group are read one group ahead.
-template <int NT, int NKG, int LSTRIDE>
-__device__ __forceinline__ void conv_tile_mfma_ilv(const float* a_frag, const float* b_frag, f32x16 (&acc)[NT]) {
-    float4 a_cur = *reinterpret_cast<const float4*>(a_frag), a_nxt = a_cur;
-    float4 b_cur[NT], b_nxt[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) b_nxt[j] = b_cur[j] = *reinterpret_cast<const float4*>(b_frag + j * 32 * LSTRIDE);
-#pragma unroll
-    for (int kg = 0; kg < NKG; ++kg) {
-        if (kg + 1 < NKG) {
-            a_nxt = *reinterpret_cast<const float4*>(a_frag + 8 * (kg + 1));
-#pragma unroll
-            for (int j = 0; j < NT; ++j) b_nxt[j] = *reinterpret_cast<const float4*>(b_frag + j * 32 * LSTRIDE + 8 * (kg + 1));
-        }
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, b_cur[j].x, acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, b_cur[j].y, acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, b_cur[j].z, acc[j], 0, 0, 0);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, b_cur[j].w, acc[j], 0, 0, 0);
-        a_cur = a_nxt;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) b_cur[j] = b_nxt[j];
-    }
-}
-
-template <int NT, bool ILV = false>
+template <int NT>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
     __shared__ __attribute__((aligned(16))) float lds[(BM + NT * 32) * LDS_STRIDE];
     float* As = lds;
@@ -202,7 +179,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
         int m = m0 + srow + 32 * i;
         a_ok[i] = m < p.M;
         m = a_ok[i] ? m : 0;
-        if (p.diag == 1) m = srow + 32 * i;
         const int n = m / p.ohw;
         const int r = m - n * p.ohw;
         const int oh = r / p.OW;
@@ -260,15 +236,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
     int kh = 0, kw = 0, cc = 0;
     load_tile(kh, kw, cc);
     for (int kt = 0; kt < KT; ++kt) {
-        if (p.diag != 3) {
-            __syncthreads();  // all waves finished reading the previous tile
+        __syncthreads();  // all waves finished reading the previous tile
 #pragma unroll
-            for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(a_st + 32 * i * LDS_STRIDE) = ra[i];
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(a_st + 32 * i * LDS_STRIDE) = ra[i];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(b_st + 32 * j * LDS_STRIDE) = rb[j];
-            __syncthreads();
-        }
-        if (kt + 1 < KT && p.diag < 2) {  // prefetch next tile into registers; lands while the MFMAs below run
+        for (int j = 0; j < NT; ++j) *reinterpret_cast<float4*>(b_st + 32 * j * LDS_STRIDE) = rb[j];
+        __syncthreads();
+        if (kt + 1 < KT) {  // prefetch next tile into registers; lands while the MFMAs below run
             if (++cc == p.cchunks) {
                 cc = 0;
                 if (++kw == p.ks) {
@@ -278,10 +252,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
             }
             load_tile(kh, kw, cc);
         }
-        if (ILV)
-            conv_tile_mfma_ilv<NT, 4, LDS_STRIDE>(a_frag, b_frag, acc);
-        else
-            conv_tile_mfma<NT, 4, LDS_STRIDE>(a_frag, b_frag, acc);
+        conv_tile_mfma<NT, 4, LDS_STRIDE>(a_frag, b_frag, acc);
     }
 
     conv_epilogue<NT>(p, acc, m0, n0, wave, lrow, half);
@@ -404,143 +375,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_buf_kernel(ConvP p) {
     conv_epilogue<NT>(p, acc, m0, n0, wave, lrow, half);
 }
 
-// Variant "db16": same tile (128 x 32*NT) but BK = 16 with TWO LDS buffers and ONE barrier per K tile: the
-// staged registers of tile kt+1 are written to the other buffer in the middle of tile kt's MFMAs and the global
-// loads of tile kt+2 are issued right after, so neither the LDS write phase nor the load issue is exposed.
-// LDS 2 x (128+32*NT) x 20 floats (46 KB at NT=5) -> 3 workgroups per CU.
-static constexpr int BK2 = 16;
-static constexpr int LS2 = 20;
-
-template <int NT>
-__global__ __launch_bounds__(256, 3) void conv_mfma_db16_kernel(ConvP p) {
-    constexpr int ROWS = BM + NT * 32;
-    constexpr int BJ = (NT * 32 + 63) / 64;  // B staging passes of 64 rows
-    __shared__ __attribute__((aligned(16))) float lds[2 * ROWS * LS2];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int nwg = gridDim.x;
-    int L = blockIdx.x;
-    {
-        const int cpx = nwg >> 3;
-        if (L < (cpx << 3)) L = (L & 7) * cpx + (L >> 3);
-    }
-    const int tile_n = L % p.tiles_n;
-    const int tile_m = L / p.tiles_n;
-    const int m0 = tile_m * BM;
-    const int n0 = tile_n * (NT * 32);
-
-    // staging map: thread -> (row = tid>>2 (+64 i), 4 consecutive k = 4*(tid&3))
-    const int col4 = tid & 3;
-    const int srow = tid >> 2;
-    int a_h[2], a_w[2];
-    int64_t a_nb[2];
-    bool a_ok[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        int m = m0 + srow + 64 * i;
-        a_ok[i] = m < p.M;
-        m = a_ok[i] ? m : 0;
-        const int n = m / p.ohw;
-        const int r = m - n * p.ohw;
-        const int oh = r / p.OW;
-        const int ow = r - oh * p.OW;
-        a_h[i] = oh * p.stride - p.pad;
-        a_w[i] = ow * p.stride - p.pad;
-        a_nb[i] = (int64_t)n * p.x_bs;
-    }
-    const float* wrow[BJ];
-    bool b_ok[BJ];
-#pragma unroll
-    for (int j = 0; j < BJ; ++j) {
-        const int rr = srow + 64 * j;
-        const int n = n0 + rr;
-        b_ok[j] = rr < NT * 32 && n < p.Cout;
-        wrow[j] = p.w + (int64_t)(b_ok[j] ? n : 0) * p.Ktot;
-    }
-    const int cch = (p.Cin + BK2 - 1) / BK2;  // K chunks of 16 per tap
-
-    float4 ra[2], rb[BJ];
-    auto load_tile = [&](int kh, int kw, int cc) {
-        const int c = cc * BK2 + col4 * 4;
-        const bool cok = c < p.Cin;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int ih = a_h[i] + kh, iw = a_w[i] + kw;
-            const bool ok = a_ok[i] && cok && (unsigned)ih < (unsigned)p.IHg && (unsigned)iw < (unsigned)p.IWg;
-            if (p.ups) {
-                ih >>= 1;
-                iw >>= 1;
-            }
-            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) ra[i] = *reinterpret_cast<const float4*>(p.x + a_nb[i] + ((int64_t)ih * p.W + iw) * p.Cin + c);
-        }
-        const int kofs = (kh * p.ks + kw) * p.Cin + c;
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) {
-            rb[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (b_ok[j] && cok) rb[j] = *reinterpret_cast<const float4*>(wrow[j] + kofs);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        float* base = lds + buf * (ROWS * LS2);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(base + (srow + 64 * i) * LS2 + col4 * 4) = ra[i];
-#pragma unroll
-        for (int j = 0; j < BJ; ++j)
-            if (srow + 64 * j < NT * 32) *reinterpret_cast<float4*>(base + (BM + srow + 64 * j) * LS2 + col4 * 4) = rb[j];
-    };
-
-    f32x16 acc[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-    const int lrow = lane & 31;
-    const int half = lane >> 5;
-    const int a_off = (wave * 32 + lrow) * LS2 + 4 * half;
-    const int b_off = (BM + lrow) * LS2 + 4 * half;
-
-    auto compute = [&](int buf, int kg) {
-        const float* base = lds + buf * (ROWS * LS2);
-        conv_tile_mfma<NT, 1, LS2>(base + a_off + 8 * kg, base + b_off + 8 * kg, acc);
-    };
-    auto advance = [&](int& kh, int& kw, int& cc) {
-        if (++cc == cch) {
-            cc = 0;
-            if (++kw == p.ks) {
-                kw = 0;
-                ++kh;
-            }
-        }
-    };
-
-    const int KT = p.ks * p.ks * cch;
-    int kh = 0, kw = 0, cc = 0;
-    load_tile(kh, kw, cc);
-    store_tile(0);
-    if (KT > 1) {
-        advance(kh, kw, cc);
-        load_tile(kh, kw, cc);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int cur = kt & 1;
-        compute(cur, 0);
-        if (kt + 1 < KT) store_tile(cur ^ 1);   // tile kt+1 (its global loads were issued one tile ago)
-        if (kt + 2 < KT) {
-            advance(kh, kw, cc);
-            load_tile(kh, kw, cc);              // tile kt+2, lands during the next tile's MFMAs
-        }
-        compute(cur, 1);
-        __syncthreads();
-    }
-
-    conv_epilogue<NT>(p, acc, m0, n0, wave, lrow, half);
-}
-
 // Direct kernel for tiny K (first layer: Cin = 1, K = 9): output-write bound, weights staged in LDS as [k][Cout].
 __global__ __launch_bounds__(256) void conv_direct_lds_kernel(ConvP p) {
     extern __shared__ float wl[];  // [Ktot][Cout]
@@ -655,7 +489,8 @@ double conv2d_flops(const ConvArgs& a) {
     return 2.0 * a.N * OH * OW * (double)a.Cout * a.ks * a.ks * a.Cin;
 }
 
-// kernel variant: ConvArgs.variant >= 0 wins, else env DSD_CONV_VARIANT, else the default
+// kernel variant: 0 = default (buffer-load kernel when eligible), 1 = force the flat-load kernel.
+// ConvArgs.variant >= 0 wins, else env DSD_CONV_VARIANT, else 0.
 static int conv_variant(const ConvArgs& a) {
     if (a.variant >= 0) return a.variant;
     static const int env = [] {
@@ -689,8 +524,11 @@ const char* conv2d_variant(const ConvArgs& a) {
     if (a.Cin % 4 != 0 || Ktot < 32) return (a.Cout % 4 == 0 && (size_t)Ktot * a.Cout * 4 <= 60 * 1024) ? "conv_direct_lds" : "conv_scalar";
     const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
     const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
-    static const char* names[6] = {"", "conv_mfma<1>", "conv_mfma<2>", "conv_mfma<3>", "conv_mfma<4>", "conv_mfma<5>"};
-    return names[pick_nt(a.Cout, cdiv((int64_t)a.N * OH * OW, BM))];
+    static const char* names[3][6] = {{"", "conv_mfma<1>", "conv_mfma<2>", "conv_mfma<3>", "conv_mfma<4>", "conv_mfma<5>"},
+                                      {"", "conv_bf16x3<1>", "conv_bf16x3<2>", "conv_bf16x3<3>", "conv_bf16x3<4>", "conv_bf16x3<5>"},
+                                      {"", "conv_bf16x6<1>", "conv_bf16x6<2>", "conv_bf16x6<3>", "conv_bf16x6<4>", "conv_bf16x6<5>"}};
+    const int pr = (a.precision != PREC_F32 && conv2d_split_eligible(a)) ? a.precision : 0;
+    return names[pr][pick_nt(a.Cout, cdiv((int64_t)a.N * OH * OW, BM))];
 }
 
 void conv2d(ConvArgs a, hipStream_t s) {
@@ -729,18 +567,10 @@ void conv2d(ConvArgs a, hipStream_t s) {
     const int nt = pick_nt(a.Cout, p.tiles_m);
     p.tiles_n = cdiv(a.Cout, nt * 32);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
-    if (conv_variant(a) == 1) {
-        switch (nt) {
-            case 1: hipLaunchKernelGGL(conv_mfma_db16_kernel<1>, grid, dim3(256), 0, s, p); break;
-            case 2: hipLaunchKernelGGL(conv_mfma_db16_kernel<2>, grid, dim3(256), 0, s, p); break;
-            case 3: hipLaunchKernelGGL(conv_mfma_db16_kernel<3>, grid, dim3(256), 0, s, p); break;
-            case 4: hipLaunchKernelGGL(conv_mfma_db16_kernel<4>, grid, dim3(256), 0, s, p); break;
-            default: hipLaunchKernelGGL(conv_mfma_db16_kernel<5>, grid, dim3(256), 0, s, p); break;
-        }
-        check_launch("conv_mfma_db16");
+    if (a.precision != PREC_F32 && conv2d_split_eligible(a)) {
+        conv2d_split(a, nt, s);
         return;
     }
-    if (conv_variant(a) >= 3 && conv_variant(a) <= 5) p.diag = conv_variant(a) - 2;  // 3,4,5 -> diag 1,2,3 (timing diagnostics)
     {
         // default path: buffer-load kernel when the operands are addressable with 32-bit byte offsets
         const int64_t xb = ((int64_t)(a.N - 1) * p.x_bs + (int64_t)a.H * a.W * a.Cin) * 4;
@@ -759,17 +589,6 @@ void conv2d(ConvArgs a, hipStream_t s) {
             check_launch("conv_mfma_buf");
             return;
         }
-    }
-    if (conv_variant(a) == 2) {
-        switch (nt) {
-            case 1: hipLaunchKernelGGL((conv_mfma_kernel<1, true>), grid, dim3(256), 0, s, p); break;
-            case 2: hipLaunchKernelGGL((conv_mfma_kernel<2, true>), grid, dim3(256), 0, s, p); break;
-            case 3: hipLaunchKernelGGL((conv_mfma_kernel<3, true>), grid, dim3(256), 0, s, p); break;
-            case 4: hipLaunchKernelGGL((conv_mfma_kernel<4, true>), grid, dim3(256), 0, s, p); break;
-            default: hipLaunchKernelGGL((conv_mfma_kernel<5, true>), grid, dim3(256), 0, s, p); break;
-        }
-        check_launch("conv_mfma_ilv");
-        return;
     }
     switch (nt) {
         case 1: hipLaunchKernelGGL(conv_mfma_kernel<1>, grid, dim3(256), 0, s, p); break;

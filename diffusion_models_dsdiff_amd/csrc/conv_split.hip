@@ -1,0 +1,370 @@
+// conv_split.hip — the same implicit-GEMM convolution on the bf16 matrix cores with fp32 operands SPLIT into bf16 pieces.
+//
+// gfx950 has no TF32/xf32; its fp32-input MFMA runs at 1/16 of the bf16 rate.  An fp32 value is written exactly as a sum
+// of three bf16 values (8 + 8 + 8 significand bits): a = a1 + a2 + a3, w = w1 + w2 + w3.  With fp32 accumulation
+//   bf16x6:  a1w1 + a1w2 + a2w1 + a2w2 + a1w3 + a3w1   drops only terms <= 2^-24 |a w|  -> fp32-grade result
+//            (measured on the CPU oracle: 9e-7 rel-L2 on the full network's output, the same as fp32 re-ordering noise)
+//   bf16x3:  a1w1 + a1w2 + a2w1                         drops terms ~2^-16..2^-17 |a w| -> 1.5e-5 on the network output
+// at 6 (resp. 3) v_mfma_f32_32x32x16_bf16 per 16 k instead of 8 v_mfma_f32_32x32x2_f32: 2.67x (5.3x) fewer matrix-pipe
+// cycles.  Weights are split once at upload (split_weights); activations are split while they are staged into LDS.
+//
+// Tiling is the fp32 kernel's (conv.hip): 256 threads, 128 x 32*NT x 32 block tile, wave = 32 rows x NT column tiles,
+// buffer loads with hardware range checks, register prefetch of the next tile, fused bias/embedding/residual epilogue.
+// LDS: one plane per piece, rows of 32 bf16 padded to 80 B (ds_read_b128 fragment reads conflict-free: lane = row,
+// 8 consecutive k = 16 B, slot (5*row + const) mod 16).
+#include "kernels.h"
+
+namespace dsd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+static constexpr int SBM = 128;
+static constexpr int SBK = 32;
+static constexpr int RSB = 80;  // LDS row stride in bytes (64 B of bf16 + 16 B pad)
+static constexpr unsigned OOB = 0xFFFFFFF0u;
+
+struct SplitP {
+    const float* x;
+    const void* w;  // [NP][Cout][Ktot] bf16
+    const float* bias;
+    const float* emb;
+    const float* res;
+    float* y;
+    int64_t x_bs;
+    int N, H, W, Cin, Cout, OH, OW, ks, stride, pad, ups, emb_stride, out_nchw;
+    int M, Ktot, cchunks, IHg, IWg, tiles_m, tiles_n, ohw;
+    unsigned x_bytes, w_bytes, w_plane_bytes;
+};
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+    bf16x2 t;
+    t[0] = (__bf16)a;
+    t[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ float bf_lo(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float bf_hi(unsigned pk) { return __builtin_bit_cast(float, pk & 0xFFFF0000u); }
+
+// split 4 fp32 into NP bf16 pieces each; out[p] = 4 packed bf16 (8 bytes)
+template <int NP>
+__device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NP]) {
+    float a = v.x, b = v.y, c = v.z, d = v.w;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const unsigned p01 = pk_bf16(a, b), p23 = pk_bf16(c, d);
+        out[p].x = p01;
+        out[p].y = p23;
+        if (p + 1 < NP) {
+            a -= bf_lo(p01);
+            b -= bf_hi(p01);
+            c -= bf_lo(p23);
+            d -= bf_hi(p23);
+        }
+    }
+}
+
+template <int NT, int NP>
+__global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
+    constexpr int BROWS = NT * 32;
+    constexpr int A_PLANE = SBM * RSB, B_PLANE = BROWS * RSB;
+    constexpr int NBL = (BROWS * 4 * NP + 255) / 256;  // 16-byte weight loads per thread per tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NP * (A_PLANE + B_PLANE)];
+    unsigned char* As = lds;
+    unsigned char* Bs = lds + NP * A_PLANE;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int nwg = gridDim.x;
+    int L = blockIdx.x;
+    {
+        const int cpx = nwg >> 3;
+        if (L < (cpx << 3)) L = (L & 7) * cpx + (L >> 3);
+    }
+    const int tile_n = L % p.tiles_n;
+    const int tile_m = L / p.tiles_n;
+    const int m0 = tile_m * SBM;
+    const int n0 = tile_n * BROWS;
+
+    // ---- A staging: thread -> (row = tid>>3 (+32 i), 4 consecutive k = 4*(tid&7)), fp32 in HBM, split on the fly
+    const int col4 = tid & 7;
+    const int srow = tid >> 3;
+    int a_h[4], a_w[4];
+    unsigned a_nb[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = m0 + srow + 32 * i;
+        a_ok[i] = m < p.M;
+        m = a_ok[i] ? m : 0;
+        const int n = m / p.ohw;
+        const int r = m - n * p.ohw;
+        const int oh = r / p.OW;
+        const int ow = r - oh * p.OW;
+        a_h[i] = oh * p.stride - p.pad;
+        a_w[i] = ow * p.stride - p.pad;
+        a_nb[i] = (unsigned)n * (unsigned)p.x_bs + (unsigned)(col4 * 4);
+    }
+    unsigned a_voff[4];
+    auto tap_offsets = [&](int kh, int kw) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int ih = a_h[i] + kh, iw = a_w[i] + kw;
+            const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.IHg && (unsigned)iw < (unsigned)p.IWg;
+            if (p.ups) {
+                ih >>= 1;
+                iw >>= 1;
+            }
+            a_voff[i] = ok ? (a_nb[i] + (unsigned)(ih * p.W + iw) * (unsigned)p.Cin) * 4u : OOB;
+        }
+    };
+    // ---- B staging: pre-split bf16 planes; 16-byte chunk q = tid + 256 i  ->  (piece, row, chunk of 8 k)
+    unsigned b_voff[NBL];
+    int b_lds[NBL];
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) {
+        const int q = tid + 256 * i;
+        const int piece = q / (BROWS * 4);
+        const int rem = q - piece * (BROWS * 4);
+        const int row = rem >> 2, ch = rem & 3;
+        const int n = n0 + row;
+        const bool ok = piece < NP && n < p.Cout;
+        b_voff[i] = ok ? (unsigned)piece * p.w_plane_bytes + ((unsigned)n * (unsigned)p.Ktot) * 2u + (unsigned)(ch * 16) : OOB;
+        b_lds[i] = piece < NP ? piece * B_PLANE + row * RSB + ch * 16 : -1;
+    }
+
+    f32x4 ra[4];
+    u32x4 rb[NBL];
+    auto load_tile = [&](int soff_a, int soff_b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[i], soff_a, 0));
+#pragma unroll
+        for (int i = 0; i < NBL; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff_b, 0);
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 pc[NP];
+            split4<NP>(ra[i], pc);
+#pragma unroll
+            for (int q = 0; q < NP; ++q)
+                *reinterpret_cast<u32x2*>(As + q * A_PLANE + (srow + 32 * i) * RSB + col4 * 8) = pc[q];
+        }
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+            if (b_lds[i] >= 0) *reinterpret_cast<u32x4*>(Bs + b_lds[i]) = rb[i];
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int lrow = lane & 31;
+    const int half = lane >> 5;
+    const unsigned char* a_frag = As + (wave * 32 + lrow) * RSB + half * 16;
+    const unsigned char* b_frag = Bs + lrow * RSB + half * 16;
+
+    auto mfma_group = [&](const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], f32x16& c) {
+        // smallest terms first
+        if (NP == 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    };
+
+    const int KT = p.ks * p.ks * p.cchunks;
+    int kh = 0, kw = 0, cc = 0, tap = 0;
+    tap_offsets(0, 0);
+    load_tile(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();
+        store_tile();
+        __syncthreads();
+        if (kt + 1 < KT) {
+            if (++cc == p.cchunks) {
+                cc = 0;
+                ++tap;
+                if (++kw == p.ks) {
+                    kw = 0;
+                    ++kh;
+                }
+                tap_offsets(kh, kw);
+            }
+            load_tile(cc * (SBK * 4), (tap * p.Cin + cc * SBK) * 2);
+        }
+        // two k-steps of 16; fragments of group (s, j+1) are read before the MFMAs of group (s, j)
+        bf16x8 a_cur[NP], b_cur[NP], b_nxt[NP], a_nxt[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            a_cur[q] = *reinterpret_cast<const bf16x8*>(a_frag + q * A_PLANE);
+            b_cur[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE);
+            a_nxt[q] = a_cur[q];
+            b_nxt[q] = b_cur[q];
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (j + 1 < NT) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        b_nxt[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE + (j + 1) * 32 * RSB + s * 32);
+                } else if (s == 0) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) {
+                        b_nxt[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE + 32);
+                        a_nxt[q] = *reinterpret_cast<const bf16x8*>(a_frag + q * A_PLANE + 32);
+                    }
+                }
+                mfma_group(a_cur, b_cur, acc[j]);
+#pragma unroll
+                for (int q = 0; q < NP; ++q) b_cur[q] = b_nxt[q];
+                if (j == NT - 1) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) a_cur[q] = a_nxt[q];
+                }
+            }
+        }
+    }
+
+    // ---- epilogue (same as the fp32 kernel): bias + per-(sample,channel) embedding + residual
+    const bool interior = (m0 + SBM <= p.M) && (n0 + BROWS <= p.Cout) && !p.out_nchw;
+    if (interior) {
+        float bj[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bj[j] = p.bias ? p.bias[n0 + j * 32 + lrow] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int mb = m0 + wave * 32 + 8 * g + 4 * half;
+            float ev[4][NT], rv[4][NT];
+            if (p.emb) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float* er = p.emb + (int64_t)((mb + rr) / p.ohw) * p.emb_stride + n0 + lrow;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) ev[rr][j] = er[j * 32];
+                }
+            }
+            if (p.res) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float* rp = p.res + (int64_t)(mb + rr) * p.Cout + n0 + lrow;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) rv[rr][j] = rp[j * 32];
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float* yp = p.y + (int64_t)(mb + rr) * p.Cout + n0 + lrow;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    float v = acc[j][4 * g + rr] + bj[j];
+                    if (p.emb) v += ev[rr][j];
+                    if (p.res) v += rv[rr][j];
+                    yp[j * 32] = v;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= p.M) continue;
+        const int nb = m / p.ohw;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 32 + lrow;
+            if (n >= p.Cout) continue;
+            float v = acc[j][r];
+            if (p.bias) v += p.bias[n];
+            if (p.emb) v += p.emb[(int64_t)nb * p.emb_stride + n];
+            if (p.res) v += p.res[(int64_t)m * p.Cout + n];
+            if (p.out_nchw)
+                p.y[((int64_t)nb * p.Cout + n) * p.ohw + (m - nb * p.ohw)] = v;
+            else
+                p.y[(int64_t)m * p.Cout + n] = v;
+        }
+    }
+}
+
+// w (fp32, [rows][K], K contiguous) -> planes[NP][rows][K] bf16, w = sum of the planes up to 2^-24 relative
+__global__ void split_weights_kernel(const float* __restrict__ w, int64_t n, int np, unsigned short* __restrict__ planes) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float r = w[i];
+        for (int q = 0; q < np; ++q) {
+            const __bf16 b = (__bf16)r;
+            planes[(int64_t)q * n + i] = __builtin_bit_cast(unsigned short, b);
+            r -= (float)b;
+        }
+    }
+}
+
+void split_weights(const float* w, int64_t n, int np, void* planes, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)), dim3(256), 0, s, w, n, np,
+                       (unsigned short*)planes);
+    check_launch("split_weights");
+}
+
+bool conv2d_split_eligible(const ConvArgs& a) {
+    if (a.Cin % SBK != 0 || a.w_split == nullptr) return false;
+    const int64_t x_bs = a.x_bs >= 0 ? a.x_bs : (int64_t)a.H * a.W * a.Cin;
+    const int64_t xb = ((int64_t)(a.N - 1) * x_bs + (int64_t)a.H * a.W * a.Cin) * 4;
+    const int64_t wb = (int64_t)a.Cout * a.ks * a.ks * a.Cin * 2 * 3;
+    return xb < 0xFFFFFF00ll && wb < 0xFFFFFF00ll;
+}
+
+template <int NP>
+static void launch_split(const SplitP& p, int nt, hipStream_t s) {
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    switch (nt) {
+        case 1: hipLaunchKernelGGL((conv_split_kernel<1, NP>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_split_kernel<2, NP>), grid, dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((conv_split_kernel<3, NP>), grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((conv_split_kernel<4, NP>), grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((conv_split_kernel<5, NP>), grid, dim3(256), 0, s, p); break;
+    }
+    check_launch("conv_split");
+}
+
+void conv2d_split(const ConvArgs& a, int nt, hipStream_t s) {
+    SplitP p{};
+    p.x = a.x; p.w = a.w_split; p.bias = a.bias; p.emb = a.emb; p.res = a.res; p.y = a.y;
+    p.N = a.N; p.H = a.H; p.W = a.W; p.Cin = a.Cin; p.Cout = a.Cout; p.ks = a.ks; p.stride = a.stride;
+    p.pad = a.ks / 2; p.ups = a.ups; p.emb_stride = a.emb_stride; p.out_nchw = a.out_nchw;
+    p.x_bs = a.x_bs >= 0 ? a.x_bs : (int64_t)a.H * a.W * a.Cin;
+    p.IHg = a.ups ? a.H * 2 : a.H;
+    p.IWg = a.ups ? a.W * 2 : a.W;
+    p.OH = (p.IHg + 2 * p.pad - a.ks) / a.stride + 1;
+    p.OW = (p.IWg + 2 * p.pad - a.ks) / a.stride + 1;
+    p.ohw = p.OH * p.OW;
+    p.M = (int)((int64_t)a.N * p.ohw);
+    p.Ktot = a.ks * a.ks * a.Cin;
+    p.cchunks = a.Cin / SBK;
+    p.tiles_m = cdiv(p.M, SBM);
+    p.tiles_n = cdiv(a.Cout, nt * 32);
+    const int np = a.precision == PREC_BF16X3 ? 2 : 3;
+    p.x_bytes = (unsigned)(((int64_t)(a.N - 1) * p.x_bs + (int64_t)a.H * a.W * a.Cin) * 4);
+    p.w_plane_bytes = (unsigned)((int64_t)a.Cout * p.Ktot * 2);
+    p.w_bytes = p.w_plane_bytes * 3u;   // planes are always stored 3 deep; bf16x3 reads the first two
+    if (np == 2)
+        launch_split<2>(p, nt, s);
+    else
+        launch_split<3>(p, nt, s);
+}
+
+}  // namespace dsd

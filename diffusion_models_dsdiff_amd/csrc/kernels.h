@@ -21,8 +21,15 @@ struct ConvArgs {
     int out_nchw = 0;           // store as [N,Cout,OH,OW] (final layer with out_channels > 1)
     int OH = 0, OW = 0;         // filled by conv2d()
     int variant = -1;           // kernel variant override (-1 = default / env DSD_CONV_VARIANT)
+    int precision = 0;          // PREC_F32 | PREC_BF16X3 | PREC_BF16X6 (conv_split.hip)
+    const void* w_split = nullptr;  // [3][Cout][ks*ks*Cin] bf16 pieces of w (needed for the split precisions)
 };
+enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16X6 = 2 };
 void conv2d(ConvArgs a, hipStream_t s);
+// conv_split.hip: fp32 operands as sums of bf16 pieces on the bf16 matrix cores
+void split_weights(const float* w, int64_t n, int np, void* planes, hipStream_t s);
+bool conv2d_split_eligible(const ConvArgs& a);
+void conv2d_split(const ConvArgs& a, int nt, hipStream_t s);
 double conv2d_flops(const ConvArgs& a);
 const char* conv2d_variant(const ConvArgs& a);   // name of the kernel conv2d() will launch for these arguments
 void pack_ohwi(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, hipStream_t s);

@@ -373,6 +373,13 @@ void dsd::net_set_param(dsd_handle* h, const char* name, const float* src, const
         if (!src_is_device) DSD_HIP(hipStreamSynchronize(s));
     }
     p.set = true;
+    auto sp = h->wsplit.find(p.name.size() > 7 ? p.name.substr(0, p.name.size() - 7) : p.name);   // "<conv>.weight" -> "<conv>"
+    if (sp != h->wsplit.end()) {
+        DSD_HIP(hipDeviceSynchronize());
+        (void)hipFree(sp->second);
+        h->wsplit.erase(sp);
+        h->plan.valid = false;
+    }
 }
 
 void dsd::net_free(dsd_handle* h) {
@@ -383,6 +390,8 @@ void dsd::net_free(dsd_handle* h) {
     if (h->mout) (void)hipFree(h->mout);
     if (h->zplane) (void)hipFree(h->zplane);
     if (h->freqs) (void)hipFree(h->freqs);
+    for (auto& kv : h->wsplit) (void)hipFree(kv.second);
+    h->wsplit.clear();
 }
 
 // =============================================================================================== builder
@@ -447,6 +456,18 @@ struct Builder {
         Tn y;
         if (!to_out) y = alloc(x.n, OH, OW, cout);
         if (res) DSD_CHECK(res->n == x.n && res->h == OH && res->w == OW && res->c == cout, "conv %s: residual shape mismatch", name.c_str());
+        if (hd->precision != PREC_F32 && x.c % 32 == 0 && plane < 0) {   // split-bf16 arithmetic: pieces of the (packed) weight
+            auto it = hd->wsplit.find(name);
+            if (it == hd->wsplit.end()) {
+                void* planes = nullptr;
+                DSD_HIP(hipMalloc(&planes, (size_t)pw.numel * 2 * 3));
+                split_weights(a.w, pw.numel, 3, planes, nullptr);
+                DSD_HIP(hipStreamSynchronize(nullptr));
+                it = hd->wsplit.emplace(name, planes).first;
+            }
+            a.w_split = it->second;
+            a.precision = hd->precision;
+        }
         const size_t xoff = x.off, yoff = y.off, roff = res ? res->off : 0;
         const bool has_res = res != nullptr;
         EmbRef e;

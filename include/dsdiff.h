@@ -79,6 +79,13 @@ int dsd_set_param(dsd_handle* h, const char* name, const float* src, const int64
  * 1-ulp difference in f to ~6e-5, so a host that wants bit-identical arguments supplies its table; without
  * it the library evaluates exp in fp64 and rounds once. */
 int dsd_set_timestep_freqs(dsd_handle* h, const float* freqs_host, int n);
+/* Arithmetic of the convolutions (99 % of the FLOPs): DSD_PREC_F32 = v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma
+ * chain); DSD_PREC_BF16X6 = every fp32 operand split exactly into three bf16 pieces, six bf16 MFMA products with fp32
+ * accumulation (drops only terms <= 2^-24: fp32-grade, ~1e-6 on the network output); DSD_PREC_BF16X3 = two pieces, three
+ * products (~1.5e-5 on the network output, still inside the 1e-4 bar of the sampled image).  Default: DSD_PREC_F32. */
+enum { DSD_PREC_F32 = 0, DSD_PREC_BF16X3 = 1, DSD_PREC_BF16X6 = 2 };
+int dsd_set_precision(dsd_handle* h, int precision);
+int dsd_get_precision(dsd_handle* h);
 /* 0 if every parameter has been set, else -1 with the first missing name in dsd_last_error(). */
 int dsd_params_ready(dsd_handle* h);
 
@@ -168,8 +175,14 @@ int dsd_block_forward(dsd_handle* h, const float* x, int B, int C, int H, int W,
  * upsample=1 folds a nearest x2 in front of the conv (Upsample, openaimodel.py:111-121). */
 int dsd_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
                   int ks, int stride, int upsample, const float* emb, const float* res, float* y, void* stream);
+/* Same with an explicit arithmetic mode: 0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6 (fp32 operands split into bf16 pieces,
+ * fp32 accumulation; conv_split.hip).  Shapes the split kernel cannot take fall back to fp32. */
+int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
+                       int ks, int stride, int upsample, const float* emb, const float* res, int precision, float* y,
+                       void* stream);
 /* Micro-benchmark of the convolution kernel on random data (library-owned buffers): average ms per launch over
- * `iters` back-to-back launches (hipEvents) and the algorithmic FLOPs of one launch.  variant: -1 default. */
+ * `iters` back-to-back launches (hipEvents) and the algorithmic FLOPs of one launch.  variant: -1/0 default fp32
+ * kernel, 1 flat-load fp32 kernel, 10 bf16x3, 11 bf16x6. */
 int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride, int variant, int iters, float* avg_ms,
                      double* flops);
 /* GroupNorm(32, C, eps) [+ SiLU] on x[N,HW,C]. */

@@ -59,8 +59,14 @@ CONV_CASES = [
 ]
 
 
+# arithmetic modes of the convolution: fp32 MFMA (exact fmaf chain), bf16x6 (fp32 split into 3 bf16 pieces, 6 products:
+# fp32-grade), bf16x3 (2 pieces, 3 products: ~2^-16 per product).  Tolerances are rel-L2 vs float64.
+PREC_TOL = {"f32": 2e-6, "bf16x6": 2e-6, "bf16x3": 3e-5}
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_vs_torch_cpu(ops, case):
+def test_conv2d_vs_torch_cpu(ops, case, prec):
     N, H, W, Cin, Cout, ks, stride, ups = case
     g = torch.Generator().manual_seed(sum(case[:6]) + 7)
     x = torch.randn(N, Cin, H, W, generator=g)
@@ -68,11 +74,28 @@ def test_conv2d_vs_torch_cpu(ops, case):
     b = torch.randn(Cout, generator=g)
     xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
     ref = F.conv2d(xin.double(), w.double(), b.double(), stride=stride, padding=ks // 2)
-    y = ops.conv2d(cu(ops.to_nhwc(x)), cu(w), cu(b), stride=stride, upsample=ups)
-    assert rel_l2(ops.to_nchw(y), ref) < 2e-6
+    y = ops.conv2d(cu(ops.to_nhwc(x)), cu(w), cu(b), stride=stride, upsample=ups, precision=prec)
+    assert rel_l2(ops.to_nchw(y), ref) < PREC_TOL[prec]
 
 
-def test_conv2d_epilogue_emb_and_residual(ops):
+def test_conv2d_split_extreme_magnitudes(ops):
+    """bf16 pieces keep fp32's exponent range: tiny and huge operands, exact zeros, and denormal-scale residuals."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 64, 8, 8, generator=g)
+    x[:, :16] *= 1e-20
+    x[:, 16:32] *= 1e18
+    x[:, 32:40] = 0.0
+    w = torch.randn(32, 64, 3, 3, generator=g) / 24.0
+    w[:8] *= 1e-10
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    for prec in ("bf16x6", "bf16x3"):
+        y = ops.conv2d(cu(ops.to_nhwc(x)), cu(w), None, precision=prec)
+        assert bool(torch.isfinite(y).all())
+        assert rel_l2(ops.to_nchw(y), ref) < PREC_TOL[prec], prec
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x6"])
+def test_conv2d_epilogue_emb_and_residual(ops, prec):
     g = torch.Generator().manual_seed(5)
     x = torch.randn(3, 64, 8, 8, generator=g)
     w = torch.randn(96, 64, 3, 3, generator=g) / 24.0
@@ -80,7 +103,7 @@ def test_conv2d_epilogue_emb_and_residual(ops):
     emb = torch.randn(3, 96, generator=g)
     res = torch.randn(3, 96, 8, 8, generator=g)
     ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + emb.double()[:, :, None, None] + res.double()
-    y = ops.conv2d(cu(ops.to_nhwc(x)), cu(w), cu(b), emb=cu(emb), res=cu(ops.to_nhwc(res)))
+    y = ops.conv2d(cu(ops.to_nhwc(x)), cu(w), cu(b), emb=cu(emb), res=cu(ops.to_nhwc(res)), precision=prec)
     assert rel_l2(ops.to_nchw(y), ref) < 2e-6
 
 
