@@ -78,8 +78,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel hipEvent pass")
     ap.add_argument("--model-channels", type=int, default=None, help="override (debug only; invalidates the metric)")
-    ap.add_argument("--precision", default=os.environ.get("DSD_PRECISION", "f32"), choices=["f32", "bf16x6", "bf16x3"],
-                    help="arithmetic of the convolutions (include/dsdiff.h: dsd_set_precision)")
+    ap.add_argument("--precision", default=os.environ.get("DSD_PRECISION", "bf16x6"), choices=["f32", "bf16x6", "bf16x3"],
+                    help="arithmetic of the convolutions (include/dsdiff.h: dsd_set_precision); default = library default")
+    ap.add_argument("--no-modes", action="store_true", help="do not also time the other arithmetic modes")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -145,65 +146,92 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up (plans the workspace, touches every weight), then K timed steps
-    if args.warmup > 0:
-        x = run_device_loop(model, sched, x, cond, seed=1234, first_step=0, n_steps=args.warmup)
-    else:
-        _lib.check(_lib.lib().dsd_plan(model._h, B, 2, H, W))
-    barrier()
-    t1 = time.time()
-    x = run_device_loop(model, sched, x, cond, seed=1234, first_step=args.warmup, n_steps=args.steps)
-    barrier()
-    dt = time.time() - t1
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    ms_per_step = dt / args.steps * 1e3
-    finite = bool(torch.isfinite(x).all())
-    info = model.plan_info()
-    slices_per_s = (B * world) / (1000.0 * ms_per_step / 1e3)
+    peak_bf16 = 2500.0
 
-    roofline = None
-    kernels = None
-    if not args.no_profile and rank == 0:
-        model.profile(True)
-        run_device_loop(model, sched, x, cond, seed=1234, first_step=args.warmup + args.steps, n_steps=2)
-        rep, runs = model.profile_report()
-        model.profile(False)
-        tot_ms = sum(v["ms"] for v in rep.values())
-        dom = max(rep.items(), key=lambda kv: kv[1]["ms"])
-        dk, dv = dom
-        ach = dv["flops"] / (dv["ms"] / 1e3) / 1e12
-        traffic = None
-        # HBM bytes per launch from the committed PMC passes of this same command (tools/pmc_summary.py;
-        # separate --pmc runs, FETCH_SIZE x2 on gfx950, KiB -> bytes): counters cannot be read live.
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(pmc):
-            try:
-                want = dk.replace("conv_mfma<", "conv_mfma_kernel<")
-                for kname, e in json.load(open(pmc)).items():
-                    if want in kname:
-                        traffic = e.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "mfma", "kernel": dk, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                    "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                    "launches_per_step": dv["calls"] // max(runs, 1),
-                    "avg_launch_ms": round(dv["ms"] / max(dv["calls"], 1), 4),
-                    "flops_per_launch": dv["flops"] / max(dv["calls"], 1),
-                    "share_of_step_time": round(dv["ms"] / tot_ms, 4),
-                    "whole_step_tflops": round(info["flops"] / (ms_per_step / 1e3) / 1e12, 2),
-                    "whole_step_frac": round(info["flops"] / (ms_per_step / 1e3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}
-        kernels = {}
-        for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
-            e = {"ms_per_step": round(v["ms"] / runs, 3), "calls_per_step": v["calls"] // runs}
-            if v["flops"] > 0:
-                e["tflops"] = round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2)
-            if v["bytes"] > 0:
-                e["gbs"] = round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1)
-                e["hbm_frac"] = round(e["gbs"] / PEAK_HBM_GBS, 4)
-            kernels[k] = e
+    def measure(precision, steps, warmup, profile_steps):
+        """K timed denoising steps in one arithmetic mode (+ optional per-kernel hipEvent pass on rank 0)."""
+        nonlocal x
+        model.set_precision(precision)
+        if warmup > 0:
+            x = run_device_loop(model, sched, x, cond, seed=1234, first_step=0, n_steps=warmup)
+        else:
+            _lib.check(_lib.lib().dsd_plan(model._h, B, 2, H, W))
+        barrier()
+        t1 = time.time()
+        x = run_device_loop(model, sched, x, cond, seed=1234, first_step=warmup, n_steps=steps)
+        barrier()
+        dt = time.time() - t1
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        ms = dt / steps * 1e3
+        info = model.plan_info()
+        res = {"precision": precision, "ms_per_step": round(ms, 3), "value": round((B * world) / (1000.0 * ms / 1e3), 6),
+               "whole_step_tflops": round(info["flops"] / (ms / 1e3) / 1e12, 2), "finite": bool(torch.isfinite(x).all()),
+               "info": info, "roofline": None, "kernels": None}
+        if profile_steps > 0 and rank == 0:
+            model.profile(True)
+            run_device_loop(model, sched, x, cond, seed=1234, first_step=warmup + steps, n_steps=profile_steps)
+            rep, runs = model.profile_report()
+            model.profile(False)
+            tot_ms = sum(v["ms"] for v in rep.values())
+            dk, dv = max(rep.items(), key=lambda kv: kv[1]["ms"])
+            ach = dv["flops"] / (dv["ms"] / 1e3) / 1e12
+            passes = {"f32": 1, "bf16x6": 6, "bf16x3": 3}[precision]
+            traffic = None
+            # HBM bytes per launch from the committed PMC passes of this same command (tools/pmc_summary.py;
+            # separate --pmc runs, FETCH_SIZE x2 on gfx950, KiB -> bytes): counters cannot be read live.
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
+            if os.path.exists(pmc):
+                try:
+                    want = {"f32": "conv_mfma_buf_kernel<5>", "bf16x6": "conv_split_kernel<5, 3>",
+                            "bf16x3": "conv_split_kernel<5, 2>"}[precision]
+                    for kname, e in json.load(open(pmc)).items():
+                        if want in kname:
+                            traffic = e.get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            # achieved = ALGORITHMIC FLOPs (2*MAC of the fp32 convolution) / measured time.  peak = the fp32 matrix peak
+            # in every mode (SURVEY.md 8d: "if bf16x3 is used, still report against fp32 peak and state the bf16 peak"):
+            # the split modes issue `passes` bf16 MFMAs per fp32 product, so frac > 1 is possible there.
+            res["roofline"] = {"bound": "mfma", "kernel": dk, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                               "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+                               "peak_note": "fp32-input MFMA dense peak (157.3); bf16 dense MFMA peak is 2500",
+                               "issued_mfma_tflops": round(ach * passes, 1),
+                               "issued_frac_of_issued_dtype_peak": round(ach * passes / (PEAK_FP32_MFMA_TFLOPS if passes == 1 else peak_bf16), 4),
+                               "launches_per_step": dv["calls"] // max(runs, 1),
+                               "avg_launch_ms": round(dv["ms"] / max(dv["calls"], 1), 4),
+                               "flops_per_launch": dv["flops"] / max(dv["calls"], 1),
+                               "share_of_step_time": round(dv["ms"] / tot_ms, 4),
+                               "whole_step_tflops": res["whole_step_tflops"],
+                               "whole_step_frac": round(res["whole_step_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)}
+            kern = {}
+            for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
+                e = {"ms_per_step": round(v["ms"] / runs, 3), "calls_per_step": v["calls"] // runs}
+                if v["flops"] > 0:
+                    e["tflops"] = round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2)
+                if v["bytes"] > 0:
+                    e["gbs"] = round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1)
+                    e["hbm_frac"] = round(e["gbs"] / PEAK_HBM_GBS, 4)
+                kern[k] = e
+            res["kernels"] = kern
+        return res
+
+    main_res = measure(args.precision, args.steps, args.warmup, 0 if args.no_profile else 2)
+    ms_per_step, slices_per_s = main_res["ms_per_step"], main_res["value"]
+    info, finite, roofline, kernels = main_res["info"], main_res["finite"], main_res["roofline"], main_res["kernels"]
+    # the other arithmetic modes, measured in the same process (single-GPU runs only; 2 steps each)
+    modes = {args.precision: {k: main_res[k] for k in ("ms_per_step", "value", "whole_step_tflops")}}
+    if world == 1 and not args.no_modes:
+        for pr in ("f32", "bf16x6", "bf16x3"):
+            if pr == args.precision:
+                continue
+            r = measure(pr, 2, 1, 0 if args.no_profile else 1)
+            modes[pr] = {k: r[k] for k in ("ms_per_step", "value", "whole_step_tflops")}
+            if r["roofline"]:
+                modes[pr]["dominant_kernel"] = {k: r["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")}
+        model.set_precision(args.precision)
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
@@ -222,7 +250,8 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": {"f32": "f32", "bf16x6": "f32 (operands split exactly into 3 bf16 pieces, 6 bf16-MFMA products, f32 accumulate)",
+                      "bf16x3": "bf16x3 (2 bf16 pieces per f32 operand, 3 products, f32 accumulate)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "configs[1]: v2-1-cddpm-ds-disc.yaml U-Net, 256x256 1->1-ch, 1000-step DDPM, "
                                    f"batch {B} per GPU; a step = 1 of the 1000 denoising steps for the whole batch",
@@ -231,6 +260,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "kernels": kernels,
+            "modes": modes,
             "extra": {"gpu": gpu_name, "compute_units": n_cu, "finite_output": finite,
                       "workspace_GiB": round(info["workspace_bytes"] / 2 ** 30, 2), "launches_per_step": info["launches"],
                       "executed_flops_per_step": info["flops"],

@@ -142,21 +142,23 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
 
     f32x4 ra[4];
     u32x4 rb[NBL];
+    u32x2 pa[4][NP];   // bf16 pieces of the staged A rows (split during the previous tile's MFMAs)
     auto load_tile = [&](int soff_a, int soff_b) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[i], soff_a, 0));
 #pragma unroll
         for (int i = 0; i < NBL; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff_b, 0);
     };
+    auto split_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) split4<NP>(ra[i], pa[i]);
+    };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            u32x2 pc[NP];
-            split4<NP>(ra[i], pc);
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int q = 0; q < NP; ++q)
-                *reinterpret_cast<u32x2*>(As + q * A_PLANE + (srow + 32 * i) * RSB + col4 * 8) = pc[q];
-        }
+                *reinterpret_cast<u32x2*>(As + q * A_PLANE + (srow + 32 * i) * RSB + col4 * 8) = pa[i][q];
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
             if (b_lds[i] >= 0) *reinterpret_cast<u32x4*>(Bs + b_lds[i]) = rb[i];
@@ -185,15 +187,39 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
     };
 
+    // one k-step (16 k) of the staged tile: fragments of group j+1 are read before the MFMAs of group j
+    auto kstep = [&](int s) {
+        bf16x8 a_cur[NP], b_cur[NP], b_nxt[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            a_cur[q] = *reinterpret_cast<const bf16x8*>(a_frag + q * A_PLANE + s * 32);
+            b_cur[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE + s * 32);
+            b_nxt[q] = b_cur[q];
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (j + 1 < NT) {
+#pragma unroll
+                for (int q = 0; q < NP; ++q)
+                    b_nxt[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE + (j + 1) * 32 * RSB + s * 32);
+            }
+            mfma_group(a_cur, b_cur, acc[j]);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) b_cur[q] = b_nxt[q];
+        }
+    };
+
     const int KT = p.ks * p.ks * p.cchunks;
     int kh = 0, kw = 0, cc = 0, tap = 0;
     tap_offsets(0, 0);
     load_tile(0, 0);
+    split_tile();
     for (int kt = 0; kt < KT; ++kt) {
         __syncthreads();
         store_tile();
         __syncthreads();
-        if (kt + 1 < KT) {
+        const bool more = kt + 1 < KT;
+        if (more) {
             if (++cc == p.cchunks) {
                 cc = 0;
                 ++tap;
@@ -205,39 +231,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
             }
             load_tile(cc * (SBK * 4), (tap * p.Cin + cc * SBK) * 2);
         }
-        // two k-steps of 16; fragments of group (s, j+1) are read before the MFMAs of group (s, j)
-        bf16x8 a_cur[NP], b_cur[NP], b_nxt[NP], a_nxt[NP];
-#pragma unroll
-        for (int q = 0; q < NP; ++q) {
-            a_cur[q] = *reinterpret_cast<const bf16x8*>(a_frag + q * A_PLANE);
-            b_cur[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE);
-            a_nxt[q] = a_cur[q];
-            b_nxt[q] = b_cur[q];
-        }
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (j + 1 < NT) {
-#pragma unroll
-                    for (int q = 0; q < NP; ++q)
-                        b_nxt[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE + (j + 1) * 32 * RSB + s * 32);
-                } else if (s == 0) {
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) {
-                        b_nxt[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE + 32);
-                        a_nxt[q] = *reinterpret_cast<const bf16x8*>(a_frag + q * A_PLANE + 32);
-                    }
-                }
-                mfma_group(a_cur, b_cur, acc[j]);
-#pragma unroll
-                for (int q = 0; q < NP; ++q) b_cur[q] = b_nxt[q];
-                if (j == NT - 1) {
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) a_cur[q] = a_nxt[q];
-                }
-            }
-        }
+        kstep(0);
+        if (more) split_tile();   // VALU work of the NEXT tile, issued in the shadow of this tile's MFMAs
+        kstep(1);
     }
 
     // ---- epilogue (same as the fp32 kernel): bias + per-(sample,channel) embedding + residual

@@ -97,7 +97,7 @@ struct dsd_handle {
     float* zplane = nullptr;   // [H*W] zeros
     float* freqs = nullptr;    // [model_channels/2] optional timestep-embedding frequency table (host-supplied)
     // arithmetic mode of the convolutions (PREC_*): bf16 pieces of each conv weight are made lazily at plan time
-    int precision = 0;
+    int precision = dsd::PREC_BF16X6;
     std::unordered_map<std::string, void*> wsplit;   // parameter name -> [3][numel] bf16 planes
     // per-kernel profiling (dsd_profile_*): hipEvents around every op of the plan on the caller's stream
     bool profiling = false;

@@ -82,7 +82,9 @@ int dsd_set_timestep_freqs(dsd_handle* h, const float* freqs_host, int n);
 /* Arithmetic of the convolutions (99 % of the FLOPs): DSD_PREC_F32 = v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma
  * chain); DSD_PREC_BF16X6 = every fp32 operand split exactly into three bf16 pieces, six bf16 MFMA products with fp32
  * accumulation (drops only terms <= 2^-24: fp32-grade, ~1e-6 on the network output); DSD_PREC_BF16X3 = two pieces, three
- * products (~1.5e-5 on the network output, still inside the 1e-4 bar of the sampled image).  Default: DSD_PREC_F32. */
+ * products (~1.5e-5 on the network output, still inside the 1e-4 bar of the sampled image).
+ * Default: DSD_PREC_BF16X6 (all parity tests hold at the fp32 tolerances); shapes the split kernel cannot take
+ * (Cin % 32 != 0, operands >= 4 GiB) use the fp32 kernels in every mode. */
 enum { DSD_PREC_F32 = 0, DSD_PREC_BF16X3 = 1, DSD_PREC_BF16X6 = 2 };
 int dsd_set_precision(dsd_handle* h, int precision);
 int dsd_get_precision(dsd_handle* h);

@@ -133,6 +133,27 @@ def test_model_forward_golden(key):
         assert rel_l2(y, yo) < tol
 
 
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-6), ("bf16x6", 5e-6), ("bf16x3", 1e-4)])
+def test_model_precision_modes(prec, tol):
+    """Every arithmetic mode of the convolutions against the reference fixture (C_in = 4: no degenerate GroupNorm group).
+    bf16x6 must hold the fp32 tolerance; bf16x3 only the 1e-4 bar of the north star (measured ~2e-5)."""
+    g, m, params = tiny_native("tiny")
+    m.set_precision(prec)
+    assert m.precision == prec
+    x = randn((2, 4, 32, 32), 71)
+    y, _ = m(x.cuda(), torch.tensor([999, 17]).cuda())
+    assert rel_l2(y, g["tiny_c4_int_y"]) < tol
+
+
+def test_default_precision_is_fp32_grade():
+    from diffusion_models_dsdiff_amd.UNet_DS_Diff.model import DSUnetModel
+    import os
+    if os.environ.get("DSD_PRECISION"):
+        pytest.skip("DSD_PRECISION overrides the default")
+    m = DSUnetModel(**json.loads(str(golden("model")["tiny_cfg"])))
+    assert m.precision == "bf16x6"
+
+
 def test_model_default_init_is_zero_like_reference():
     """zero_module() sites make the reference's output identically 0 at default init (SURVEY.md headline fact 3)."""
     from diffusion_models_dsdiff_amd.UNet_DS_Diff.model import DSUnetModel
@@ -190,11 +211,16 @@ def test_full_config_forward_vs_oracle(full_model):
     for C, seed in ((2, 5), (4, 6)):
         x = randn((1, C, 64, 64), seed)
         t = torch.tensor([731])
-        y, feats = m(x.cuda(), t.cuda())
         yo, fo = O.unet_forward(cfg, sd, x, t)
         assert float(yo.abs().max()) > 1e-3                              # non-vacuous: zero_module sites re-randomised
-        assert rel_l2(y, yo) < 1e-5, C
-        assert rel_l2(torch.stack(feats["style"]), torch.stack(fo["style"])) < 1e-5
+        for prec, tol in (("bf16x6", 1e-5), ("f32", 1e-5), ("bf16x3", 1e-4)):
+            m.set_precision(prec)
+            y, feats = m(x.cuda(), t.cuda())
+            err = rel_l2(y, yo)
+            print(f"full-config forward C={C} {prec}: rel-L2 {err:.3e}")
+            assert err < tol, (C, prec)
+            assert rel_l2(torch.stack(feats["style"]), torch.stack(fo["style"])) < tol
+    m.set_precision("bf16x6")
 
 
 def test_full_config_ddpm_chain_vs_oracle(full_model):
@@ -209,7 +235,11 @@ def test_full_config_ddpm_chain_vs_oracle(full_model):
     z = randn((1000,) + shape, 13)
     d = create_gaussian_diffusion(steps=1000, parameterization="v")
     sched = d._schedule(False, 0.0, True)
-    y = run_device_loop(m, sched, x_start.cuda(), cond.cuda(), step_noise=z.cuda(), first_step=1000 - n, n_steps=n)
+    ys = {}
+    for prec in ("bf16x6", "f32", "bf16x3"):
+        m.set_precision(prec)
+        ys[prec] = run_device_loop(m, sched, x_start.cuda(), cond.cuda(), step_noise=z.cuda(), first_step=1000 - n, n_steps=n)
+    m.set_precision("bf16x6")
     od = OS.DiffusionA(steps=1000, parameterization="v")
     model = lambda xx, tt: O.unet_forward(cfg, sd, xx, tt)[0]
     img = x_start
@@ -218,7 +248,10 @@ def test_full_config_ddpm_chain_vs_oracle(full_model):
         t = torch.tensor([i])
         mean, log_var, _ = od.p_mean_variance(model, img, t, True, [cond])
         img = mean + (t != 0).float().view(-1, 1, 1, 1) * torch.exp(0.5 * log_var) * z[k]
-    assert rel_l2(y, img) < 1e-4
+    for prec, y in ys.items():
+        err = rel_l2(y, img)
+        print(f"full-config 40-step DDPM chain {prec}: rel-L2 {err:.3e}")
+        assert err < 1e-4, prec
 
 
 def cond_image_(shape, seed):
