@@ -232,6 +232,15 @@ def main():
             if r["roofline"]:
                 modes[pr]["dominant_kernel"] = {k: r["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")}
         model.set_precision(args.precision)
+        # separate line (never part of `value`): the two zero-input streams evaluated once per step instead of per slice
+        model.share_zero_streams(True)
+        r = measure(args.precision, 2, 1, 0)
+        model.share_zero_streams(False)
+        modes[args.precision + "+share_zero_streams"] = {
+            "ms_per_step": r["ms_per_step"], "value": r["value"], "executed_flops_per_step": r["info"]["flops"],
+            "note": "output bit-identical; 2 of the 4 encoder streams have all-zero input in the 1->1-channel case and are "
+                    "computed at batch 1 (SURVEY.md 7: must be reported separately)"}
+        _lib.check(_lib.lib().dsd_plan(model._h, B, 2, H, W))
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:

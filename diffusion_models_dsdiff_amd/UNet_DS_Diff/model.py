@@ -80,6 +80,11 @@ class NativeModule(nn.Module):
         check(lib().dsd_set_precision(self._h, _lib.PRECISIONS[precision]))
         return self
 
+    def share_zero_streams(self, on: bool = True):
+        """Sampling loops only (see include/dsdiff.h: dsd_set_share_zero_streams); off by default."""
+        check(lib().dsd_set_share_zero_streams(self._h, int(on)))
+        return self
+
     @property
     def precision(self) -> str:
         code = lib().dsd_get_precision(self._h)

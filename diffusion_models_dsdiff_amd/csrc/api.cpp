@@ -188,6 +188,13 @@ int dsd_set_precision(dsd_handle* h, int precision) {
 
 int dsd_get_precision(dsd_handle* h) { return h ? h->precision : -1; }
 
+int dsd_set_share_zero_streams(dsd_handle* h, int on) {
+    DSD_TRY
+    DSD_CHECK(h && !h->is_block, "needs a model handle");
+    h->share_zero_streams = on != 0;
+    DSD_CATCH
+}
+
 int dsd_params_ready(dsd_handle* h) {
     DSD_TRY
     DSD_CHECK(h, "null handle");
@@ -292,7 +299,7 @@ int dsd_sample(dsd_handle* h, const dsd_schedule* sc, const float* cond, int Cc,
     set_device(h->device);
     hipStream_t s = (hipStream_t)stream;
     const int64_t hw = (int64_t)H * W;
-    net_plan(h, B, Cc + 1, H, W, Cc == 1, 0, 0, 0);
+    net_plan(h, B, Cc + 1, H, W, Cc == 1, 0, 0, 0, (Cc == 1 && B > 1) ? h->share_zero_streams : 0);
     ensure_buf(&h->tbuf, &h->tbuf_cap, (size_t)B * sizeof(float));
     ensure_buf(&h->mout, &h->mout_cap, (size_t)B * out_ch * hw * sizeof(float));
     // DiffusionWrapper 'concat' (ddpm.py:1331-1333) without materialising the cat: streams read planes in place

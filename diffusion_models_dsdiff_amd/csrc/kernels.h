@@ -66,8 +66,9 @@ void linear(const float* x, int N, int K, int ldx, const float* w, const float* 
             int ldy, hipStream_t s);
 void se_scale(const float* x, int N, int HW, int C, const float* w1, const float* w2, int Cr, float* y, hipStream_t s);
 // dst[p, coff:coff+C] = act((a+b+c+d) * scale), sources NHWC [pixels][C]
+// bmask bit k: source k is ONE sample ([per_sample_pixels][C]) broadcast over the batch of dst
 void avg_into(const float* a, const float* b, const float* c, const float* d, float scale, int64_t pixels, int C,
-              float* dst, int dstC, int coff, int act, hipStream_t s);
+              float* dst, int dstC, int coff, int act, hipStream_t s, int64_t per_sample_pixels = 0, int bmask = 0);
 void nchw_to_nhwc(const float* x, int N, int C, int HW, float* y, hipStream_t s);
 void nhwc_to_nchw(const float* x, int N, int C, int HW, float* y, hipStream_t s);
 void avgpool2(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);

@@ -136,12 +136,14 @@ template <int ACT>
 __global__ __launch_bounds__(256) void avg_into_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
                                                        const float4* __restrict__ c, const float4* __restrict__ d,
                                                        float div, int64_t total4, int cols, float* __restrict__ dst,
-                                                       int dstC, int coff) {
+                                                       int dstC, int coff, int64_t per_sample4, int bmask) {
+    // bmask bit k set: source k holds ONE sample that is shared by (broadcast over) the whole batch
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-        float4 v = a[i];
-        if (b) { const float4 t = b[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-        if (c) { const float4 t = c[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
-        if (d) { const float4 t = d[i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        const int64_t is = bmask ? i % per_sample4 : i;
+        float4 v = a[(bmask & 1) ? is : i];
+        if (b) { const float4 t = b[(bmask & 2) ? is : i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (c) { const float4 t = c[(bmask & 4) ? is : i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        if (d) { const float4 t = d[(bmask & 8) ? is : i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
         if (div != 1.f) { v.x /= div; v.y /= div; v.z /= div; v.w /= div; }
         if (ACT == ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
         const int64_t p = i / cols;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void avg_into_kernel(const float4* __restrict_
 }
 
 void avg_into(const float* a, const float* b, const float* c, const float* d, float div, int64_t pixels, int C, float* dst,
-              int dstC, int coff, int act, hipStream_t s) {
+              int dstC, int coff, int act, hipStream_t s, int64_t per_sample_pixels, int bmask) {
     DSD_CHECK(C % 4 == 0 && dstC % 4 == 0 && coff % 4 == 0, "avg_into: channel counts must be multiples of 4");
     const int cols = C / 4;
     const int64_t total = pixels * cols;
@@ -159,10 +161,10 @@ void avg_into(const float* a, const float* b, const float* c, const float* d, fl
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 32);
     if (act == ACT_SILU)
         hipLaunchKernelGGL(avg_into_kernel<ACT_SILU>, dim3(blocks), dim3(256), 0, s, (const float4*)a, (const float4*)b,
-                           (const float4*)c, (const float4*)d, div, total, cols, dst, dstC, coff);
+                           (const float4*)c, (const float4*)d, div, total, cols, dst, dstC, coff, per_sample_pixels * cols, bmask);
     else
         hipLaunchKernelGGL(avg_into_kernel<ACT_NONE>, dim3(blocks), dim3(256), 0, s, (const float4*)a, (const float4*)b,
-                           (const float4*)c, (const float4*)d, div, total, cols, dst, dstC, coff);
+                           (const float4*)c, (const float4*)d, div, total, cols, dst, dstC, coff, per_sample_pixels * cols, bmask);
     check_launch("avg_into");
 }
 

@@ -646,16 +646,23 @@ struct Builder {
     // dst[:, coff:coff+C] = act((a+b+c+d)/div)
     void avg(const Tn* srcs, int nsrc, float div, const Tn& dst, int coff, int act) {
         size_t o[4] = {0, 0, 0, 0};
-        for (int i = 0; i < nsrc; ++i) o[i] = srcs[i].off;
+        int bmask = 0;
+        for (int i = 0; i < nsrc; ++i) {
+            o[i] = srcs[i].off;
+            DSD_CHECK(srcs[i].n == dst.n || srcs[i].n == 1, "avg: batch mismatch");
+            if (srcs[i].n == 1 && dst.n > 1) bmask |= 1 << i;   // one shared sample, broadcast over the batch
+        }
         const int C = srcs[0].c;
-        const int64_t pixels = (int64_t)srcs[0].n * srcs[0].hw();
+        const int64_t pixels = (int64_t)dst.n * dst.hw();
+        const int64_t per_sample = dst.hw();
         const size_t doff = dst.off;
         const int dstC = dst.c;
         dsd_handle* h = hd;
         op([=](hipStream_t s) {
             const float* p[4] = {nullptr, nullptr, nullptr, nullptr};
             for (int i = 0; i < nsrc; ++i) p[i] = reinterpret_cast<const float*>(h->arena + o[i]);
-            avg_into(p[0], p[1], p[2], p[3], div, pixels, C, reinterpret_cast<float*>(h->arena + doff), dstC, coff, act, s);
+            avg_into(p[0], p[1], p[2], p[3], div, pixels, C, reinterpret_cast<float*>(h->arena + doff), dstC, coff, act, s,
+                     per_sample, bmask);
         }, 1, nsrc == 4 ? "skip_avg4_concat" : "concat_copy", 0.0, 4.0 * pixels * C * (nsrc + 1));
     }
 
@@ -791,14 +798,15 @@ struct Builder {
 };
 
 // --------------------------------------------------------------------------------- DSUnetModel.forward
-void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats) {
+void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats, bool share) {
     dsd_handle* hd = b.hd;
     const dsd_config& cfg = hd->cfg;
     const Spec sp = build_spec(cfg);
     const int B = b.B;
     const int nds = cfg.n_levels - 1;
     DSD_CHECK(H % (1 << nds) == 0 && W % (1 << nds) == 0, "H=%d, W=%d must be multiples of %d (down/up-sampling + skip concat)", H, W, 1 << nds);
-    (void)zero_al_l;
+    // share: the al / l streams see the same (all-zero) plane and the same timestep for every slice -> batch of ONE
+    DSD_CHECK(!share || (zero_al_l && !want_feats), "zero-stream sharing needs the 2-channel branch and no feature outputs");
 
     // ---- timestep embedding MLP + all 68 emb_layers as ONE GEMM (model.py:645-646; openaimodel.py:222-228,273)
     const int mc = cfg.model_channels, ted = sp.ted;
@@ -856,7 +864,7 @@ void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats) {
         const std::string base = std::string("input_blocks") + sfx[s];
         auto embs = embs_for(base, sp.input_blocks);
         Tn cur;
-        cur.n = B; cur.h = H; cur.w = W; cur.c = 1;  // the caller's plane
+        cur.n = (share && s >= 2) ? 1 : B; cur.h = H; cur.w = W; cur.c = 1;  // the caller's plane
         for (size_t bi = 0; bi < sp.input_blocks.size(); ++bi) {
             size_t ei = 0;
             Tn nxt = b.block(base + "." + std::to_string(bi), sp.input_blocks[bi], cur, /*keep_input=*/true, embs[bi], ei,
@@ -894,7 +902,9 @@ void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats) {
         n_content = b.disentangle("conv_content", h_n, half);
     }
     auto proj = [&](const std::string& nm, Tn* list, int n) {
-        Tn m = b.alloc(B, list[0].h, list[0].w, half);
+        int nb = 1;
+        for (int i = 0; i < n; ++i) nb = std::max(nb, list[i].n);
+        Tn m = b.alloc(nb, list[0].h, list[0].w, half);
         b.avg(list, n, (float)n, m, 0, ACT_NONE);           // ht.mean(ht.stack(list), dim=0)
         Tn se = b.se(nm + ".0", m);
         b.release(m);
@@ -1033,22 +1043,23 @@ void build_block(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
 
 }  // namespace
 
-void dsd::net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int want_feats, int aux_len, int aux_len2) {
+void dsd::net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int want_feats, int aux_len, int aux_len2,
+                   int share) {
     Plan& p = h->plan;
     if (p.valid && p.B == B && p.C == C && p.H == H && p.W == W && p.zero_al_l == zero_al_l && p.want_feats == want_feats &&
-        p.aux_len == aux_len && p.aux_len2 == aux_len2)
+        p.aux_len == aux_len && p.aux_len2 == aux_len2 && p.share == share)
         return;
     DSD_CHECK(h->device >= 0, "this handle was created without a device (table only)");
     for (const auto& prm : h->params) DSD_CHECK(prm.set, "parameter '%s' has not been set", prm.name.c_str());
     DSD_CHECK(B >= 1 && H >= 1 && W >= 1, "empty input");
     p = Plan{};
     p.B = B; p.C = C; p.H = H; p.W = W; p.zero_al_l = zero_al_l; p.want_feats = want_feats;
-    p.aux_len = aux_len; p.aux_len2 = aux_len2;
+    p.aux_len = aux_len; p.aux_len2 = aux_len2; p.share = share;
     Builder b(h, p, B);
     if (h->is_block)
         build_block(b, C, H, W, aux_len, aux_len2);
     else
-        build_unet(b, H, W, zero_al_l != 0, want_feats != 0);
+        build_unet(b, H, W, zero_al_l != 0, want_feats != 0, share != 0);
     p.arena_bytes = b.ar.peak + 256;
     if (p.arena_bytes > h->arena_cap) {
         DSD_HIP(hipDeviceSynchronize());

@@ -53,7 +53,7 @@ struct IO {
 
 struct Plan {
     int B = 0, H = 0, W = 0, C = 0;
-    int zero_al_l = 0, want_feats = 0;
+    int zero_al_l = 0, want_feats = 0, share = 0;
     int aux_len = 0, aux_len2 = 0;
     bool valid = false;
     std::vector<std::function<void(hipStream_t)>> ops;
@@ -98,6 +98,9 @@ struct dsd_handle {
     float* freqs = nullptr;    // [model_channels/2] optional timestep-embedding frequency table (host-supplied)
     // arithmetic mode of the convolutions (PREC_*): bf16 pieces of each conv weight are made lazily at plan time
     int precision = dsd::PREC_BF16X6;
+    // dsd_sample only: evaluate the two all-zero-input streams of the C_in = 2 branch ONCE per step instead of once per
+    // slice (bit-identical results: same input, same timestep for every slice of the batch).  Off by default.
+    int share_zero_streams = 0;
     std::unordered_map<std::string, void*> wsplit;   // parameter name -> [3][numel] bf16 planes
     // per-kernel profiling (dsd_profile_*): hipEvents around every op of the plan on the caller's stream
     bool profiling = false;
@@ -116,7 +119,8 @@ namespace dsd {
 void net_declare_params(dsd_handle* h);
 void net_set_param(dsd_handle* h, const char* name, const float* src, const int64_t* shape, int ndim, int src_is_device,
                    hipStream_t s);
-void net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int want_feats, int aux_len, int aux_len2);
+void net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int want_feats, int aux_len, int aux_len2,
+              int share = 0);
 void net_run(dsd_handle* h, hipStream_t s);
 void net_free(dsd_handle* h);
 }  // namespace dsd

@@ -88,6 +88,12 @@ int dsd_set_timestep_freqs(dsd_handle* h, const float* freqs_host, int n);
 enum { DSD_PREC_F32 = 0, DSD_PREC_BF16X3 = 1, DSD_PREC_BF16X6 = 2 };
 int dsd_set_precision(dsd_handle* h, int precision);
 int dsd_get_precision(dsd_handle* h);
+/* dsd_sample only, OFF by default.  In the 2-channel branch (model.py:654-658) the `al` and `l` encoder streams get
+ * zeros_like(x) as input and, inside a sampling loop, the same timestep for every slice: their activations are identical
+ * across the batch.  With this option they are evaluated once per step (batch of one) and broadcast where they join the
+ * other streams — bit-identical output, 28 % fewer FLOPs at batch 16.  It is work the reference performs redundantly, so
+ * it is never enabled silently and bench.py reports it as a separate line; dsd_plan_flops() counts what is executed. */
+int dsd_set_share_zero_streams(dsd_handle* h, int on);
 /* 0 if every parameter has been set, else -1 with the first missing name in dsd_last_error(). */
 int dsd_params_ready(dsd_handle* h);
 

@@ -128,3 +128,26 @@ def test_philox_sampling_is_seeded_and_batch_independent(env):
     one = d.ddim_sample_loop(wrap, (1,) + SHAPE[1:], noise=xT[:1], model_kwargs=dict(c_concat=[cond[:1]]))
     assert rel_l2(one, full[:1]) < 1e-5
     assert bool(torch.isfinite(a).all())
+
+
+def test_share_zero_streams_is_bit_identical(env):
+    """Optional dedup of the two all-zero-input streams (dsd_set_share_zero_streams): same bits, fewer FLOPs."""
+    from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
+    gl, wrap, cond, xT, _ = env
+    d = create_gaussian_diffusion(steps=1000, timestep_respacing="20", rescale_timesteps=True, parameterization="v")
+    unet = wrap.diffusion_model
+    shape = (4, 1, 32, 32)
+    c4, x4 = torch.cat([cond, cond.flip(0)]), torch.cat([xT, xT.flip(0)])
+    kw = dict(noise=x4, model_kwargs=dict(c_concat=[c4]), seed=77)
+    for prec in ("bf16x6", "f32"):
+        unet.set_precision(prec)
+        unet.share_zero_streams(False)
+        a = d.p_sample_loop(wrap, shape, **kw)
+        f0 = unet.plan_info()["flops"]
+        unet.share_zero_streams(True)
+        b = d.p_sample_loop(wrap, shape, **kw)
+        f1 = unet.plan_info()["flops"]
+        unet.share_zero_streams(False)
+        assert torch.equal(a, b), prec
+        assert f1 < 0.85 * f0
+    unet.set_precision("bf16x6")
