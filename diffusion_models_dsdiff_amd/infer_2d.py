@@ -30,6 +30,7 @@ def main(argv=None):
     ap.add_argument("--output", required=True)
     ap.add_argument("--ckpt", default=None, help="torch state_dict file (plain tensors; keys may carry model.diffusion_model.)")
     ap.add_argument("--synthetic-weights", type=int, default=None, help="seed: random-init weights (no checkpoint)")
+    ap.add_argument("--x-T", default=None, help=".npy [N,1,H,W] start noise (default: torch.randn per batch, as the reference)")
     args = ap.parse_args(argv)
 
     from . import parallel
@@ -88,6 +89,7 @@ def main(argv=None):
     extra = {"eta": float(ss.get("ddim_eta", 0))} if ss.get("sampler", "ddpm") == "ddim" else {}
 
     cond_all = np.load(args.input, mmap_mode="r")
+    xT_all = np.load(args.x_T, mmap_mode="r") if args.x_T else None
     n = cond_all.shape[0]
     mine = parallel.shard_indices(n, rank, ws)
     bs = int(icfg.get("test_batch_size", 16))
@@ -96,7 +98,8 @@ def main(argv=None):
         idx = mine[i:i + bs]
         images = torch.from_numpy(np.ascontiguousarray(cond_all[idx])).float().to(dev)
         B, _, H, W = images.shape
-        outs.append(sample_fn(unet, (B, 1, H, W), clip_denoised=bool(mp.get("clip_denoised", True)),
+        noise = None if xT_all is None else torch.from_numpy(np.ascontiguousarray(xT_all[idx])).float().to(dev)
+        outs.append(sample_fn(unet, (B, 1, H, W), noise=noise, clip_denoised=bool(mp.get("clip_denoised", True)),
                               model_kwargs=dict(c_concat=[images]), **extra))
     local_out = torch.cat(outs) if outs else torch.zeros((0, 1) + tuple(cond_all.shape[2:]), device=dev)
     full = parallel.gather_slices(local_out, n, 0)
