@@ -372,6 +372,13 @@ int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride,
     a.x = x.as<float>(); a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.w = w.as<float>(); a.bias = b.as<float>();
     a.Cout = Cout; a.ks = ks; a.stride = stride; a.y = y.as<float>(); a.variant = variant >= 10 ? -1 : variant;
     Tmp planes(nw * 2 * 3);
+    if (variant >= 30) {  // 30 = bf16x3 A-direct, 31 = bf16x6 A-direct (forced)
+        a.variant = 30;
+        variant -= 20;
+    } else if (variant >= 20) {  // 20 = bf16x3 staged, 21 = bf16x6 staged (forced)
+        a.variant = 31;
+        variant -= 10;
+    }
     if (variant >= 10) {  // 10 = bf16x3, 11 = bf16x6
         split_weights(w.as<float>(), (int64_t)nw, 3, planes.p, s);
         a.w_split = planes.p;
@@ -404,10 +411,12 @@ int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float
     ConvArgs a;
     a.x = x; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.w = wp.as<float>(); a.bias = bias; a.Cout = Cout; a.ks = ks;
     a.stride = stride; a.ups = upsample; a.emb = emb; a.emb_stride = Cout; a.res = res; a.y = y;
-    if (precision != PREC_F32) {
+    if ((precision & 3) != PREC_F32) {
         split_weights(wp.as<float>(), (int64_t)nw, 3, planes.p, s);
         a.w_split = planes.p;
-        a.precision = precision;
+        a.precision = precision & 3;
+        if (precision & 16) a.variant = 30;   // force the A-direct structure
+        if (precision & 32) a.variant = 31;   // force the staged structure
     }
     conv2d(a, s);
     DSD_HIP(hipStreamSynchronize(s));

@@ -8,11 +8,19 @@
 // at 6 (resp. 3) v_mfma_f32_32x32x16_bf16 per 16 k instead of 8 v_mfma_f32_32x32x2_f32: 2.67x (5.3x) fewer matrix-pipe
 // cycles.  Weights are split once at upload (split_weights); activations are split while they are staged into LDS.
 //
+// Three structures were measured (tools/bench_conv.py; 16x256x256x320->320, bf16x6 / bf16x3 TF/s of fp32-equivalent work):
+// both operands staged through LDS 188 / 319 (conv_split_kernel); activations read straight into registers 199 / 322
+// (conv_split_ad_kernel, used for bf16x6 on the large layers); producer/consumer wave specialisation with two LDS stages
+// 165 / 326 (removed).  PMC: clock 1.88 GHz under bf16 load, 6 x 195 = 1.17 PF/s issued = 47 % of the nominal bf16 peak,
+// in the range hand-tuned bf16 GEMMs reach on this part (MI355X_MICROARCH.md "DVFS give-back").
+//
 // Tiling is the fp32 kernel's (conv.hip): 256 threads, 128 x 32*NT x 32 block tile, wave = 32 rows x NT column tiles,
 // buffer loads with hardware range checks, register prefetch of the next tile, fused bias/embedding/residual epilogue.
 // LDS: one plane per piece, rows of 32 bf16 padded to 80 B (ds_read_b128 fragment reads conflict-free: lane = row,
 // 8 consecutive k = 16 B, slot (5*row + const) mod 16).
 #include "kernels.h"
+
+#include <cstdlib>
 
 namespace dsd {
 
@@ -64,6 +72,71 @@ __device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NP]) {
             b -= bf_hi(p01);
             c -= bf_lo(p23);
             d -= bf_hi(p23);
+        }
+    }
+}
+
+// ---- accumulators -> memory: bias + per-(sample,channel) embedding + residual (same fusion as the fp32 kernel)
+template <int NT>
+__device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&acc)[NT], int m0, int n0, int wave, int lrow,
+                                               int half) {
+    constexpr int BROWS = NT * 32;
+    const bool interior = (m0 + SBM <= p.M) && (n0 + BROWS <= p.Cout) && !p.out_nchw;
+    if (interior) {
+        float bj[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bj[j] = p.bias ? p.bias[n0 + j * 32 + lrow] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int mb = m0 + wave * 32 + 8 * g + 4 * half;
+            float ev[4][NT], rv[4][NT];
+            if (p.emb) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float* er = p.emb + (int64_t)((mb + rr) / p.ohw) * p.emb_stride + n0 + lrow;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) ev[rr][j] = er[j * 32];
+                }
+            }
+            if (p.res) {
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) {
+                    const float* rp = p.res + (int64_t)(mb + rr) * p.Cout + n0 + lrow;
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) rv[rr][j] = rp[j * 32];
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                float* yp = p.y + (int64_t)(mb + rr) * p.Cout + n0 + lrow;
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    float v = acc[j][4 * g + rr] + bj[j];
+                    if (p.emb) v += ev[rr][j];
+                    if (p.res) v += rv[rr][j];
+                    yp[j * 32] = v;
+                }
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (m >= p.M) continue;
+        const int nb = m / p.ohw;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int n = n0 + j * 32 + lrow;
+            if (n >= p.Cout) continue;
+            float v = acc[j][r];
+            if (p.bias) v += p.bias[n];
+            if (p.emb) v += p.emb[(int64_t)nb * p.emb_stride + n];
+            if (p.res) v += p.res[(int64_t)m * p.Cout + n];
+            if (p.out_nchw)
+                p.y[((int64_t)nb * p.Cout + n) * p.ohw + (m - nb * p.ohw)] = v;
+            else
+                p.y[(int64_t)m * p.Cout + n] = v;
         }
     }
 }
@@ -236,65 +309,171 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
         kstep(1);
     }
 
-    // ---- epilogue (same as the fp32 kernel): bias + per-(sample,channel) embedding + residual
-    const bool interior = (m0 + SBM <= p.M) && (n0 + BROWS <= p.Cout) && !p.out_nchw;
-    if (interior) {
-        float bj[NT];
+    split_epilogue<NT>(p, acc, m0, n0, wave, lrow, half);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// "A-direct" variant (256 threads): the activation operand never touches LDS.  In the MFMA A layout a lane owns ONE row
+// (output pixel) and 8 consecutive k, which is 32 contiguous bytes of the NHWC fp32 tensor — so every lane loads its own
+// fragment straight from global memory (2 x 16 B per k-step), splits it into bf16 pieces in registers and feeds the MFMA.
+// Only the weight tile (shared by the four waves) is staged through LDS.  This removes 24 KB of LDS writes and 24 KB of LDS
+// reads per block tile (LDS was 42 % busy with 30 % of that in bank conflicts in the staged kernel, PMC).
+template <int NP>
+__device__ __forceinline__ void split8(f32x4 lo, f32x4 hi, bf16x8 (&out)[NP]) {
+    u32x2 pl[NP], ph[NP];
+    split4<NP>(lo, pl);
+    split4<NP>(hi, ph);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) bj[j] = p.bias ? p.bias[n0 + j * 32 + lrow] : 0.f;
+    for (int q = 0; q < NP; ++q) {
+        u32x4 v;
+        v.x = pl[q].x; v.y = pl[q].y; v.z = ph[q].x; v.w = ph[q].y;
+        out[q] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <int NT, int NP>
+__global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
+    constexpr int BROWS = NT * 32;
+    constexpr int B_PLANE = BROWS * RSB;
+    constexpr int NBL = (BROWS * 4 * NP + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[NP * B_PLANE];
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int lrow = lane & 31;
+    const int half = lane >> 5;
+    const int nwg = gridDim.x;
+    int L = blockIdx.x;
+    {
+        const int cpx = nwg >> 3;
+        if (L < (cpx << 3)) L = (L & 7) * cpx + (L >> 3);
+    }
+    const int tile_n = L % p.tiles_n;
+    const int tile_m = L / p.tiles_n;
+    const int m0 = tile_m * SBM;
+    const int n0 = tile_n * BROWS;
+
+    // ---- A: this lane's output pixel (row of the implicit GEMM) and its 8-float slot inside a 16-k step
+    int a_h, a_w;
+    unsigned a_nb;
+    bool a_ok;
+    {
+        int m = m0 + wave * 32 + lrow;
+        a_ok = m < p.M;
+        m = a_ok ? m : 0;
+        const int n = m / p.ohw;
+        const int r = m - n * p.ohw;
+        const int oh = r / p.OW;
+        const int ow = r - oh * p.OW;
+        a_h = oh * p.stride - p.pad;
+        a_w = ow * p.stride - p.pad;
+        a_nb = (unsigned)n * (unsigned)p.x_bs + (unsigned)(half * 8);
+    }
+    unsigned a_voff[4];   // the four 16-byte pieces of this lane's two 8-float slots; OOB must not wrap when offset
+    auto tap_offsets = [&](int kh, int kw) {
+        int ih = a_h + kh, iw = a_w + kw;
+        const bool ok = a_ok && (unsigned)ih < (unsigned)p.IHg && (unsigned)iw < (unsigned)p.IWg;
+        if (p.ups) {
+            ih >>= 1;
+            iw >>= 1;
+        }
+        const unsigned base = (a_nb + (unsigned)(ih * p.W + iw) * (unsigned)p.Cin) * 4u;
+        a_voff[0] = ok ? base : OOB;
+        a_voff[1] = ok ? base + 16u : OOB;
+        a_voff[2] = ok ? base + 64u : OOB;
+        a_voff[3] = ok ? base + 80u : OOB;
+    };
+    // ---- B staging (as in the staged kernel)
+    unsigned b_voff[NBL];
+    int b_lds[NBL];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int mb = m0 + wave * 32 + 8 * g + 4 * half;
-            float ev[4][NT], rv[4][NT];
-            if (p.emb) {
+    for (int i = 0; i < NBL; ++i) {
+        const int q = tid + 256 * i;
+        const int piece = q / (BROWS * 4);
+        const int rem = q - piece * (BROWS * 4);
+        const int row = rem >> 2, ch = rem & 3;
+        const int n = n0 + row;
+        const bool ok = piece < NP && n < p.Cout;
+        b_voff[i] = ok ? (unsigned)piece * p.w_plane_bytes + ((unsigned)n * (unsigned)p.Ktot) * 2u + (unsigned)(ch * 16) : OOB;
+        b_lds[i] = piece < NP ? piece * B_PLANE + row * RSB + ch * 16 : -1;
+    }
+    f32x4 ra[4];   // [k-step][lo/hi 4 floats]
+    u32x4 rb[NBL];
+    auto load_tile = [&](int soff_a, int soff_b) {
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const float* er = p.emb + (int64_t)((mb + rr) / p.ohw) * p.emb_stride + n0 + lrow;
+        for (int i = 0; i < 4; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[i], soff_a, 0));
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) ev[rr][j] = er[j * 32];
+        for (int i = 0; i < NBL; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff_b, 0);
+    };
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const unsigned char* b_frag = Bs + lrow * RSB + half * 16;
+    auto mfma_group = [&](const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], f32x16& c) {
+        if (NP == 3) {
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+        }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+    };
+
+    const int KT = p.ks * p.ks * p.cchunks;
+    int kh = 0, kw = 0, cc = 0, tap = 0;
+    tap_offsets(0, 0);
+    load_tile(0, 0);
+    bf16x8 af[2][NP];   // A fragments of the current tile (both k-steps), in registers
+    for (int kt = 0; kt < KT; ++kt) {
+        // the held registers are tile kt: split A into pieces, publish B through LDS
+        split8<NP>(ra[0], ra[1], af[0]);
+        split8<NP>(ra[2], ra[3], af[1]);
+        __syncthreads();   // every wave finished reading the previous B tile
+#pragma unroll
+        for (int i = 0; i < NBL; ++i)
+            if (b_lds[i] >= 0) *reinterpret_cast<u32x4*>(Bs + b_lds[i]) = rb[i];
+        __syncthreads();
+        if (kt + 1 < KT) {
+            if (++cc == p.cchunks) {
+                cc = 0;
+                ++tap;
+                if (++kw == p.ks) {
+                    kw = 0;
+                    ++kh;
                 }
+                tap_offsets(kh, kw);
             }
-            if (p.res) {
+            load_tile(cc * (SBK * 4), (tap * p.Cin + cc * SBK) * 2);
+        }
+        bf16x8 b_cur[NP], b_nxt[NP];
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) {
-                    const float* rp = p.res + (int64_t)(mb + rr) * p.Cout + n0 + lrow;
+        for (int q = 0; q < NP; ++q) b_nxt[q] = b_cur[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) rv[rr][j] = rp[j * 32];
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (j + 1 < NT) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q)
+                        b_nxt[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE + (j + 1) * 32 * RSB + s * 32);
+                } else if (s == 0) {
+#pragma unroll
+                    for (int q = 0; q < NP; ++q) b_nxt[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE + 32);
                 }
-            }
+                mfma_group(af[s], b_cur, acc[j]);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                float* yp = p.y + (int64_t)(mb + rr) * p.Cout + n0 + lrow;
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    float v = acc[j][4 * g + rr] + bj[j];
-                    if (p.emb) v += ev[rr][j];
-                    if (p.res) v += rv[rr][j];
-                    yp[j * 32] = v;
-                }
+                for (int q = 0; q < NP; ++q) b_cur[q] = b_nxt[q];
             }
         }
-        return;
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (m >= p.M) continue;
-        const int nb = m / p.ohw;
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int n = n0 + j * 32 + lrow;
-            if (n >= p.Cout) continue;
-            float v = acc[j][r];
-            if (p.bias) v += p.bias[n];
-            if (p.emb) v += p.emb[(int64_t)nb * p.emb_stride + n];
-            if (p.res) v += p.res[(int64_t)m * p.Cout + n];
-            if (p.out_nchw)
-                p.y[((int64_t)nb * p.Cout + n) * p.ohw + (m - nb * p.ohw)] = v;
-            else
-                p.y[(int64_t)m * p.Cout + n] = v;
-        }
-    }
+    split_epilogue<NT>(p, acc, m0, n0, wave, lrow, half);
 }
 
 // w (fp32, [rows][K], K contiguous) -> planes[NP][rows][K] bf16, w = sum of the planes up to 2^-24 relative
@@ -325,8 +504,19 @@ bool conv2d_split_eligible(const ConvArgs& a) {
 }
 
 template <int NP>
-static void launch_split(const SplitP& p, int nt, hipStream_t s) {
+static void launch_split(const SplitP& p, int nt, hipStream_t s, bool ad) {
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    if (ad) {
+        switch (nt) {
+            case 1: hipLaunchKernelGGL((conv_split_ad_kernel<1, NP>), grid, dim3(256), 0, s, p); break;
+            case 2: hipLaunchKernelGGL((conv_split_ad_kernel<2, NP>), grid, dim3(256), 0, s, p); break;
+            case 3: hipLaunchKernelGGL((conv_split_ad_kernel<3, NP>), grid, dim3(256), 0, s, p); break;
+            case 4: hipLaunchKernelGGL((conv_split_ad_kernel<4, NP>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((conv_split_ad_kernel<5, NP>), grid, dim3(256), 0, s, p); break;
+        }
+        check_launch("conv_split_ad");
+        return;
+    }
     switch (nt) {
         case 1: hipLaunchKernelGGL((conv_split_kernel<1, NP>), grid, dim3(256), 0, s, p); break;
         case 2: hipLaunchKernelGGL((conv_split_kernel<2, NP>), grid, dim3(256), 0, s, p); break;
@@ -357,10 +547,13 @@ void conv2d_split(const ConvArgs& a, int nt, hipStream_t s) {
     p.x_bytes = (unsigned)(((int64_t)(a.N - 1) * p.x_bs + (int64_t)a.H * a.W * a.Cin) * 4);
     p.w_plane_bytes = (unsigned)((int64_t)a.Cout * p.Ktot * 2);
     p.w_bytes = p.w_plane_bytes * 3u;   // planes are always stored 3 deep; bf16x3 reads the first two
+    // A-direct pays for the 3-piece mode on the large layers (+6 % on the 256^2/128^2/64^2 convs); the 2-piece mode and
+    // the small-M layers are faster with both operands staged (tools/bench_conv.py 11 31 10 30)
+    const bool ad = a.variant == 30 || (a.variant != 31 && np == 3 && (int64_t)p.tiles_m * p.tiles_n >= 512);
     if (np == 2)
-        launch_split<2>(p, nt, s);
+        launch_split<2>(p, nt, s, ad);
     else
-        launch_split<3>(p, nt, s);
+        launch_split<3>(p, nt, s, ad);
 }
 
 }  // namespace dsd

@@ -22,7 +22,10 @@ def to_nchw(x: torch.Tensor) -> torch.Tensor:
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
 
 
-def conv2d(x_nhwc, w_oihw, bias, stride=1, upsample=False, emb=None, res=None, precision="f32"):
+STRUCTURES = {"auto": 0, "adirect": 16, "staged": 32}
+
+
+def conv2d(x_nhwc, w_oihw, bias, stride=1, upsample=False, emb=None, res=None, precision="f32", structure="auto"):
     N, H, W, Cin = x_nhwc.shape
     Cout, _, ks, _ = w_oihw.shape
     IH, IW = (H * 2, W * 2) if upsample else (H, W)
@@ -30,7 +33,8 @@ def conv2d(x_nhwc, w_oihw, bias, stride=1, upsample=False, emb=None, res=None, p
     OH, OW = (IH + 2 * pad - ks) // stride + 1, (IW + 2 * pad - ks) // stride + 1
     y = torch.empty((N, OH, OW, Cout), device=x_nhwc.device, dtype=torch.float32)
     check(lib().dsd_op_conv2d_prec(dptr(x_nhwc), N, H, W, Cin, dptr(w_oihw.contiguous()), dptr(bias), Cout, ks, stride,
-                                   int(upsample), dptr(emb), dptr(res), PRECISIONS[precision], dptr(y), stream_ptr()))
+                                   int(upsample), dptr(emb), dptr(res), PRECISIONS[precision] | STRUCTURES[structure],
+                                   dptr(y), stream_ptr()))
     return y
 
 

@@ -184,13 +184,15 @@ int dsd_block_forward(dsd_handle* h, const float* x, int B, int C, int H, int W,
 int dsd_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
                   int ks, int stride, int upsample, const float* emb, const float* res, float* y, void* stream);
 /* Same with an explicit arithmetic mode: 0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6 (fp32 operands split into bf16 pieces,
- * fp32 accumulation; conv_split.hip).  Shapes the split kernel cannot take fall back to fp32. */
+ * fp32 accumulation; conv_split.hip).  Shapes the split kernel cannot take fall back to fp32.  OR-ing 16 / 32 into
+ * `precision` forces the A-direct / fully staged kernel structure (tests); otherwise the library chooses. */
 int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
                        int ks, int stride, int upsample, const float* emb, const float* res, int precision, float* y,
                        void* stream);
 /* Micro-benchmark of the convolution kernel on random data (library-owned buffers): average ms per launch over
  * `iters` back-to-back launches (hipEvents) and the algorithmic FLOPs of one launch.  variant: -1/0 default fp32
- * kernel, 1 flat-load fp32 kernel, 10 bf16x3, 11 bf16x6. */
+ * kernel, 1 flat-load fp32 kernel, 10 bf16x3, 11 bf16x6 (library's choice of structure), 20/21 both operands staged
+ * through LDS, 30/31 activations read straight into registers. */
 int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride, int variant, int iters, float* avg_ms,
                      double* flops);
 /* GroupNorm(32, C, eps) [+ SiLU] on x[N,HW,C]. */

@@ -56,6 +56,7 @@ CONV_CASES = [
     (1, 5, 7, 36, 20, 3, 1, False),       # Cin % 32 != 0 (masked K chunk), odd sizes
     (1, 4, 4, 6, 5, 3, 2, False),         # scalar fallback
     (2, 64, 64, 128, 96, 3, 1, False),
+    (2, 128, 128, 64, 320, 3, 1, False),  # >= 512 tiles: the shape class where the library itself picks the A-direct structure
 ]
 
 
@@ -78,6 +79,29 @@ def test_conv2d_vs_torch_cpu(ops, case, prec):
     assert rel_l2(ops.to_nchw(y), ref) < PREC_TOL[prec]
 
 
+@pytest.mark.parametrize("structure", ["adirect", "staged"])
+@pytest.mark.parametrize("prec", ["bf16x6", "bf16x3"])
+def test_conv2d_split_structures(ops, prec, structure):
+    """Both kernel structures of the split-bf16 convolution (the library picks per shape) on every eligible case,
+    incl. the epilogue fusions, stride 2, folded upsample and ragged M / N tiles."""
+    for case in CONV_CASES:
+        N, H, W, Cin, Cout, ks, stride, ups = case
+        if Cin % 32:
+            continue
+        g = torch.Generator().manual_seed(sum(case[:6]) + 11)
+        x = torch.randn(N, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+        b = torch.randn(Cout, generator=g)
+        xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+        ref = F.conv2d(xin.double(), w.double(), b.double(), stride=stride, padding=ks // 2)
+        emb = torch.randn(N, Cout, generator=g)
+        res = torch.randn(*ref.shape, generator=g)
+        ref = ref + emb.double()[:, :, None, None] + res.double()
+        y = ops.conv2d(cu(ops.to_nhwc(x)), cu(w), cu(b), stride=stride, upsample=ups, emb=cu(emb), res=cu(ops.to_nhwc(res)),
+                       precision=prec, structure=structure)
+        assert rel_l2(ops.to_nchw(y), ref) < PREC_TOL[prec], (case, prec, structure)
+
+
 def test_conv2d_split_extreme_magnitudes(ops):
     """bf16 pieces keep fp32's exponent range: tiny and huge operands, exact zeros, and denormal-scale residuals."""
     g = torch.Generator().manual_seed(3)
@@ -89,9 +113,10 @@ def test_conv2d_split_extreme_magnitudes(ops):
     w[:8] *= 1e-10
     ref = F.conv2d(x.double(), w.double(), None, padding=1)
     for prec in ("bf16x6", "bf16x3"):
-        y = ops.conv2d(cu(ops.to_nhwc(x)), cu(w), None, precision=prec)
-        assert bool(torch.isfinite(y).all())
-        assert rel_l2(ops.to_nchw(y), ref) < PREC_TOL[prec], prec
+        for structure in ("staged", "adirect"):
+            y = ops.conv2d(cu(ops.to_nhwc(x)), cu(w), None, precision=prec, structure=structure)
+            assert bool(torch.isfinite(y).all())
+            assert rel_l2(ops.to_nchw(y), ref) < PREC_TOL[prec], (prec, structure)
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x6"])
