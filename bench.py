@@ -86,10 +86,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal hooks (never set by the driver): run N ranks on ONE device over gloo to exercise the multi-rank code path
+    backend = os.environ.get("DSD_BENCH_BACKEND", "nccl")
+    if os.environ.get("DSD_BENCH_SINGLE_DEVICE"):
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

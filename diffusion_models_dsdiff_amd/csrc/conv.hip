@@ -500,23 +500,41 @@ static int conv_variant(const ConvArgs& a) {
     return env;
 }
 
-static int pick_nt(int Cout, int tiles_m) {
+// Column-tile count NT (block tile = 128 x 32*NT) by a small cost model fitted to tools/bench_conv.py measurements:
+//   time ~ ceil(blocks / (256 CUs x 2 resident)) x K-tiles x (t_fix + NT x t_mfma)
+// t_fix = per-tile staging/barrier cycles that do not shrink with NT, t_mfma = matrix-pipe cycles per 32 columns per
+// tile (fp32: 16 x 64, bf16x6: 12 x 32, bf16x3: 6 x 32).  Big layers get NT = 5 (weights and A staging amortised over the
+// widest tile); small-M layers get narrower tiles so the grid still fills the chip.
+static int pick_nt(int Cout, int tiles_m, int precision) {
+    static const int force = [] {
+        const char* e = getenv("DSD_FORCE_NT");   // experiments only
+        return e ? atoi(e) : 0;
+    }();
+    if (force >= 1 && force <= 5) return force;
     const int t32 = cdiv(Cout, 32);
-    int best = 1, best_waste = 1 << 30;
+    const double t_fix = precision == PREC_F32 ? 500.0 : 700.0;
+    const double t_mf = precision == PREC_F32 ? 1024.0 : (precision == PREC_BF16X6 ? 384.0 : 192.0);
+    int best = 1;
+    double best_t = 1e300;
     for (int nt = 5; nt >= 1; --nt) {
-        const int waste = cdiv(t32, nt) * nt - t32;
-        if (waste < best_waste) {
-            best_waste = waste;
+        const int64_t blocks = (int64_t)tiles_m * cdiv(t32, nt);
+        const double t = (double)cdiv(blocks, 512) * (t_fix + nt * t_mf);
+        if (t < best_t * 0.999) {
+            best_t = t;
             best = nt;
         }
     }
-    // keep >= ~2 blocks per CU on small-M layers by narrowing the N tile
-    while (best > 1 && (int64_t)tiles_m * cdiv(t32, best) < 512) {
-        int nb = best - 1;
-        while (nb > 1 && (cdiv(t32, nb) * nb - t32) > best_waste) --nb;
-        best = nb;
-    }
     return best;
+}
+
+// split-bf16 arithmetic requested and usable for this problem?  Grids of at most one block per CU are latency-bound
+// and measurably faster on the fp32 kernel (8x8 layers at batch 16: 0.195 ms vs 0.275 ms), so those stay fp32.
+static int effective_precision(const ConvArgs& a, int tiles_m) {
+    if (a.precision == PREC_F32 || !conv2d_split_eligible(a)) return PREC_F32;
+    if (a.variant == 30 || a.variant == 31) return a.precision;   // structure forced by a test
+    const int nt = pick_nt(a.Cout, tiles_m, a.precision);
+    if ((int64_t)tiles_m * cdiv(cdiv(a.Cout, 32), nt) <= 256) return PREC_F32;
+    return a.precision;
 }
 
 const char* conv2d_variant(const ConvArgs& a) {
@@ -527,8 +545,9 @@ const char* conv2d_variant(const ConvArgs& a) {
     static const char* names[3][6] = {{"", "conv_mfma<1>", "conv_mfma<2>", "conv_mfma<3>", "conv_mfma<4>", "conv_mfma<5>"},
                                       {"", "conv_bf16x3<1>", "conv_bf16x3<2>", "conv_bf16x3<3>", "conv_bf16x3<4>", "conv_bf16x3<5>"},
                                       {"", "conv_bf16x6<1>", "conv_bf16x6<2>", "conv_bf16x6<3>", "conv_bf16x6<4>", "conv_bf16x6<5>"}};
-    const int pr = (a.precision != PREC_F32 && conv2d_split_eligible(a)) ? a.precision : 0;
-    return names[pr][pick_nt(a.Cout, cdiv((int64_t)a.N * OH * OW, BM))];
+    const int tm = cdiv((int64_t)a.N * OH * OW, BM);
+    const int pr = effective_precision(a, tm);
+    return names[pr][pick_nt(a.Cout, tm, pr)];
 }
 
 void conv2d(ConvArgs a, hipStream_t s) {
@@ -564,10 +583,11 @@ void conv2d(ConvArgs a, hipStream_t s) {
         }
         return;
     }
-    const int nt = pick_nt(a.Cout, p.tiles_m);
+    const int prec = effective_precision(a, p.tiles_m);
+    const int nt = pick_nt(a.Cout, p.tiles_m, prec);
     p.tiles_n = cdiv(a.Cout, nt * 32);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
-    if (a.precision != PREC_F32 && conv2d_split_eligible(a)) {
+    if (prec != PREC_F32) {
         conv2d_split(a, nt, s);
         return;
     }
