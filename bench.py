@@ -245,7 +245,7 @@ def main():
         model.share_zero_streams(False)
         modes[args.precision + "+share_zero_streams"] = {
             "ms_per_step": r["ms_per_step"], "value": r["value"], "executed_flops_per_step": r["info"]["flops"],
-            "note": "output bit-identical; 2 of the 4 encoder streams have all-zero input in the 1->1-channel case and are "
+            "note": "same output up to fp32 rounding; 2 of the 4 encoder streams have all-zero input in the 1->1-channel case and are "
                     "computed at batch 1 (SURVEY.md 7: must be reported separately)"}
         _lib.check(_lib.lib().dsd_plan(model._h, B, 2, H, W))
 

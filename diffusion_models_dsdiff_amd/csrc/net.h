@@ -99,7 +99,7 @@ struct dsd_handle {
     // arithmetic mode of the convolutions (PREC_*): bf16 pieces of each conv weight are made lazily at plan time
     int precision = dsd::PREC_BF16X6;
     // dsd_sample only: evaluate the two all-zero-input streams of the C_in = 2 branch ONCE per step instead of once per
-    // slice (bit-identical results: same input, same timestep for every slice of the batch).  Off by default.
+    // slice (same input, same timestep for every slice of the batch -> same result).  Off by default.
     int share_zero_streams = 0;
     std::unordered_map<std::string, void*> wsplit;   // parameter name -> [3][numel] bf16 planes
     // per-kernel profiling (dsd_profile_*): hipEvents around every op of the plan on the caller's stream

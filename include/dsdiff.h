@@ -91,7 +91,8 @@ int dsd_get_precision(dsd_handle* h);
 /* dsd_sample only, OFF by default.  In the 2-channel branch (model.py:654-658) the `al` and `l` encoder streams get
  * zeros_like(x) as input and, inside a sampling loop, the same timestep for every slice: their activations are identical
  * across the batch.  With this option they are evaluated once per step (batch of one) and broadcast where they join the
- * other streams — bit-identical output, 28 % fewer FLOPs at batch 16.  It is work the reference performs redundantly, so
+ * other streams — the same output (bit-identical when the per-layer kernel choice does not change with the batch,
+ * otherwise equal to fp32 rounding, ~1e-7), 28 % fewer FLOPs at batch 16.  It is work the reference performs redundantly, so
  * it is never enabled silently and bench.py reports it as a separate line; dsd_plan_flops() counts what is executed. */
 int dsd_set_share_zero_streams(dsd_handle* h, int on);
 /* 0 if every parameter has been set, else -1 with the first missing name in dsd_last_error(). */

@@ -264,7 +264,7 @@ def test_full_size_properties(full_model):
     forward, 2.8 h per sample), so it is covered by size-independent properties on 3 denoising steps of the DDPM chain:
     the three arithmetic modes agree (f32 is bit-for-bit an fp32 fma chain and is pinned against the oracle at 64x64),
     a slice sampled alone equals the same slice inside a batch, the loop is deterministic, sharing the zero-input
-    streams changes nothing, and everything stays finite.  These shapes run the large-grid kernel choices
+    streams changes nothing beyond fp32 rounding, and everything stays finite.  These shapes run the large-grid kernel choices
     (NT = 5 tiles, A-direct structure, XCD-swizzled grids) that small cases never select."""
     from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
     from diffusion_models_dsdiff_amd._sched import run_device_loop
@@ -292,7 +292,8 @@ def test_full_size_properties(full_model):
     m.share_zero_streams(True)
     shared = run_device_loop(m, sched, xT, cond, step_noise=noise, first_step=0, n_steps=3)
     m.share_zero_streams(False)
-    assert torch.equal(shared, out["bf16x6"])                                             # bit-identical, fewer FLOPs
+    # same result (the shared streams run at batch 1, where a few layers pick a different tile/kernel: fp32 rounding only)
+    assert rel_l2(shared, out["bf16x6"]) < 1e-5
     # Philox path: same seed -> same sample, different seed -> different
     a = run_device_loop(m, sched, xT, cond, seed=5, first_step=0, n_steps=2)
     b = run_device_loop(m, sched, xT, cond, seed=5, first_step=0, n_steps=2)

@@ -131,7 +131,8 @@ def test_philox_sampling_is_seeded_and_batch_independent(env):
 
 
 def test_share_zero_streams_is_bit_identical(env):
-    """Optional dedup of the two all-zero-input streams (dsd_set_share_zero_streams): same bits, fewer FLOPs."""
+    """Optional dedup of the two all-zero-input streams (dsd_set_share_zero_streams): same bits here (the tiny model picks
+    the same kernels at batch 1 and 4; at full size the choice can differ -> test_full_size_properties), fewer FLOPs."""
     from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
     gl, wrap, cond, xT, _ = env
     d = create_gaussian_diffusion(steps=1000, timestep_respacing="20", rescale_timesteps=True, parameterization="v")
