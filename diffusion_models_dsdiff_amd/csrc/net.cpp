@@ -392,6 +392,8 @@ void dsd::net_free(dsd_handle* h) {
     if (h->freqs) (void)hipFree(h->freqs);
     for (auto& kv : h->wsplit) (void)hipFree(kv.second);
     h->wsplit.clear();
+    for (auto e : h->ev) (void)hipEventDestroy(e);
+    h->ev.clear();
 }
 
 // =============================================================================================== builder
