@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel hipEvent pass")
     ap.add_argument("--model-channels", type=int, default=None, help="override (debug only; invalidates the metric)")
-    ap.add_argument("--precision", default=os.environ.get("DSD_PRECISION", "bf16x6"), choices=["f32", "bf16x6", "bf16x3"],
+    ap.add_argument("--precision", default=os.environ.get("DSD_PRECISION", "bf16x6"), choices=["f32", "bf16x6", "bf16x3", "f16x3"],
                     help="arithmetic of the convolutions (include/dsdiff.h: dsd_set_precision); default = library default")
     ap.add_argument("--no-modes", action="store_true", help="do not also time the other arithmetic modes")
     args = ap.parse_args()
@@ -190,15 +190,15 @@ def main():
             tot_ms = sum(v["ms"] for v in rep.values())
             dk, dv = max(rep.items(), key=lambda kv: kv[1]["ms"])
             ach = dv["flops"] / (dv["ms"] / 1e3) / 1e12
-            passes = {"f32": 1, "bf16x6": 6, "bf16x3": 3}[precision]
+            passes = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "f16x3": 3}[precision]
             traffic = None
             # HBM bytes per launch from the committed PMC passes of this same command (tools/pmc_summary.py;
             # separate --pmc runs, FETCH_SIZE x2 on gfx950, KiB -> bytes): counters cannot be read live.
             pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
             if os.path.exists(pmc):
                 try:
-                    want = {"f32": ("conv_mfma_buf_kernel", "<5>"), "bf16x6": ("conv_split", "<5, 3>"),
-                            "bf16x3": ("conv_split", "<5, 2>")}[precision]
+                    want = {"f32": ("conv_mfma_buf_kernel", "<5>"), "bf16x6": ("conv_split", "<5, 3"),
+                            "bf16x3": ("conv_split", "<5, 2, false>"), "f16x3": ("conv_split", "<5, 2, true>")}[precision]
                     best = 0.0
                     for kname, e in json.load(open(pmc)).items():   # the variant with the most time under PMC
                         if want[0] in kname and want[1] in kname and e.get("total_us_under_pmc", 0) > best:
@@ -238,7 +238,7 @@ def main():
     # the other arithmetic modes, measured in the same process (single-GPU runs only; 2 steps each)
     modes = {args.precision: {k: main_res[k] for k in ("ms_per_step", "value", "whole_step_tflops")}}
     if world == 1 and not args.no_modes:
-        for pr in ("f32", "bf16x6", "bf16x3"):
+        for pr in ("f32", "bf16x6", "f16x3", "bf16x3"):
             if pr == args.precision:
                 continue
             r = measure(pr, 2, 1, 0 if args.no_profile else 1)
@@ -274,7 +274,8 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": {"f32": "f32", "bf16x6": "f32 (operands split exactly into 3 bf16 pieces, 6 bf16-MFMA products, f32 accumulate)",
-                      "bf16x3": "bf16x3 (2 bf16 pieces per f32 operand, 3 products, f32 accumulate)"}[args.precision],
+                      "bf16x3": "bf16x3 (2 bf16 pieces per f32 operand, 3 products, f32 accumulate)",
+                      "f16x3": "f16x3 (2 fp16 pieces per f32 operand, 3 products, f32 accumulate)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "configs[1]: v2-1-cddpm-ds-disc.yaml U-Net, 256x256 1->1-ch, 1000-step DDPM, "
                                    f"batch {B} per GPU; a step = 1 of the 1000 denoising steps for the whole batch",

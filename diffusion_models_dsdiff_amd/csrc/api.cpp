@@ -178,7 +178,7 @@ int dsd_set_timestep_freqs(dsd_handle* h, const float* freqs_host, int n) {
 int dsd_set_precision(dsd_handle* h, int precision) {
     DSD_TRY
     DSD_CHECK(h, "null handle");
-    DSD_CHECK(precision >= PREC_F32 && precision <= PREC_BF16X6, "unknown precision %d", precision);
+    DSD_CHECK(precision >= PREC_F32 && precision <= PREC_F16X3, "unknown precision %d", precision);
     if (h->precision != precision) {
         h->precision = precision;
         h->plan.valid = false;   // the plan bakes the kernel choice in
@@ -228,6 +228,7 @@ int dsd_forward(dsd_handle* h, const float* x, const void* t, int t_is_float, in
     h->io.out = out;
     h->io.feats = feats;
     net_run(h, s);
+    net_check_overflow(h, s);
     DSD_CATCH
 }
 
@@ -268,6 +269,7 @@ int dsd_block_forward(dsd_handle* h, const float* x, int B, int C, int H, int W,
     h->io.aux2 = aux2;
     h->io.out = out;
     net_run(h, (hipStream_t)stream);
+    net_check_overflow(h, (hipStream_t)stream);
     DSD_CATCH
 }
 
@@ -329,6 +331,7 @@ int dsd_sample(dsd_handle* h, const dsd_schedule* sc, const float* cond, int Cc,
         const StepCoef c = step_coef(sc, k);
         sampler_update(c, h->mout, x, noise ? noise + (size_t)k * B * hw : nullptr, philox_seed, (uint64_t)k, B, (int)hw, s);
     }
+    net_check_overflow(h, s);
     DSD_CATCH
 }
 
@@ -379,10 +382,10 @@ int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride,
         a.variant = 31;
         variant -= 10;
     }
-    if (variant >= 10) {  // 10 = bf16x3, 11 = bf16x6
-        split_weights(w.as<float>(), (int64_t)nw, 3, planes.p, s);
+    if (variant >= 10) {  // 10 = bf16x3, 11 = bf16x6, 12 = f16x3
+        a.precision = variant == 10 ? PREC_BF16X3 : (variant == 11 ? PREC_BF16X6 : PREC_F16X3);
+        split_weights(w.as<float>(), (int64_t)nw, 3, planes.p, s, a.precision == PREC_F16X3);
         a.w_split = planes.p;
-        a.precision = variant == 10 ? PREC_BF16X3 : PREC_BF16X6;
     }
     conv2d(a, s);  // warm-up
     hipEvent_t e0, e1;
@@ -411,15 +414,22 @@ int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float
     ConvArgs a;
     a.x = x; a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.w = wp.as<float>(); a.bias = bias; a.Cout = Cout; a.ks = ks;
     a.stride = stride; a.ups = upsample; a.emb = emb; a.emb_stride = Cout; a.res = res; a.y = y;
+    Tmp ovf(sizeof(int));
+    DSD_HIP(hipMemsetAsync(ovf.p, 0, sizeof(int), s));
     if ((precision & 3) != PREC_F32) {
-        split_weights(wp.as<float>(), (int64_t)nw, 3, planes.p, s);
+        const bool f16 = (precision & 3) == PREC_F16X3;
+        split_weights(wp.as<float>(), (int64_t)nw, 3, planes.p, s, f16, f16 ? ovf.as<int>() : nullptr);
         a.w_split = planes.p;
         a.precision = precision & 3;
+        a.ovf = f16 ? ovf.as<int>() : nullptr;
         if (precision & 16) a.variant = 30;   // force the A-direct structure
         if (precision & 32) a.variant = 31;   // force the staged structure
     }
     conv2d(a, s);
+    int flag = 0;
+    DSD_HIP(hipMemcpyAsync(&flag, ovf.p, sizeof(int), hipMemcpyDeviceToHost, s));
     DSD_HIP(hipStreamSynchronize(s));
+    DSD_CHECK(!flag, "f16x3: a convolution operand exceeded the fp16 range (|x| > 65504); the result is invalid - use bf16x6 or f32");
     DSD_CATCH
 }
 

@@ -513,7 +513,7 @@ static int pick_nt(int Cout, int tiles_m, int precision) {
     if (force >= 1 && force <= 5) return force;
     const int t32 = cdiv(Cout, 32);
     const double t_fix = precision == PREC_F32 ? 500.0 : 700.0;
-    const double t_mf = precision == PREC_F32 ? 1024.0 : (precision == PREC_BF16X6 ? 384.0 : 192.0);
+    const double t_mf = precision == PREC_F32 ? 1024.0 : (precision == PREC_BF16X6 ? 384.0 : 192.0);   // bf16x3 = f16x3
     int best = 1;
     double best_t = 1e300;
     for (int nt = 5; nt >= 1; --nt) {
@@ -542,9 +542,10 @@ const char* conv2d_variant(const ConvArgs& a) {
     if (a.Cin % 4 != 0 || Ktot < 32) return (a.Cout % 4 == 0 && (size_t)Ktot * a.Cout * 4 <= 60 * 1024) ? "conv_direct_lds" : "conv_scalar";
     const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
     const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
-    static const char* names[3][6] = {{"", "conv_mfma<1>", "conv_mfma<2>", "conv_mfma<3>", "conv_mfma<4>", "conv_mfma<5>"},
+    static const char* names[4][6] = {{"", "conv_mfma<1>", "conv_mfma<2>", "conv_mfma<3>", "conv_mfma<4>", "conv_mfma<5>"},
                                       {"", "conv_bf16x3<1>", "conv_bf16x3<2>", "conv_bf16x3<3>", "conv_bf16x3<4>", "conv_bf16x3<5>"},
-                                      {"", "conv_bf16x6<1>", "conv_bf16x6<2>", "conv_bf16x6<3>", "conv_bf16x6<4>", "conv_bf16x6<5>"}};
+                                      {"", "conv_bf16x6<1>", "conv_bf16x6<2>", "conv_bf16x6<3>", "conv_bf16x6<4>", "conv_bf16x6<5>"},
+                                      {"", "conv_f16x3<1>", "conv_f16x3<2>", "conv_f16x3<3>", "conv_f16x3<4>", "conv_f16x3<5>"}};
     const int tm = cdiv((int64_t)a.N * OH * OW, BM);
     const int pr = effective_precision(a, tm);
     return names[pr][pick_nt(a.Cout, tm, pr)];

@@ -47,31 +47,57 @@ struct SplitP {
     int N, H, W, Cin, Cout, OH, OW, ks, stride, pad, ups, emb_stride, out_nchw;
     int M, Ktot, cchunks, IHg, IWg, tiles_m, tiles_n, ohw;
     unsigned x_bytes, w_bytes, w_plane_bytes;
+    int* ovf;   // f16x3 only: set to 1 when an operand magnitude exceeds the fp16 range (caller reports it)
 };
 
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
-    bf16x2 t;
-    t[0] = (__bf16)a;
-    t[1] = (__bf16)b;
-    return __builtin_bit_cast(unsigned, t);
-}
-__device__ __forceinline__ float bf_lo(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
-__device__ __forceinline__ float bf_hi(unsigned pk) { return __builtin_bit_cast(float, pk & 0xFFFF0000u); }
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// Piece element type: bf16 (8 significand bits, fp32's exponent range) or fp16 (11 bits, range +-65504).
+template <bool F16> struct Elt;
+template <> struct Elt<false> {
+    typedef bf16x8 v8;
+    static __device__ __forceinline__ unsigned pk(float a, float b) {
+        bf16x2 t;
+        t[0] = (__bf16)a;
+        t[1] = (__bf16)b;
+        return __builtin_bit_cast(unsigned, t);
+    }
+    static __device__ __forceinline__ float lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+    static __device__ __forceinline__ float hi(unsigned p) { return __builtin_bit_cast(float, p & 0xFFFF0000u); }
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct Elt<true> {
+    typedef f16x8 v8;
+    static __device__ __forceinline__ unsigned pk(float a, float b) {
+        f16x2 t;
+        t[0] = (_Float16)a;
+        t[1] = (_Float16)b;
+        return __builtin_bit_cast(unsigned, t);
+    }
+    static __device__ __forceinline__ float lo(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[0]; }
+    static __device__ __forceinline__ float hi(unsigned p) { return (float)__builtin_bit_cast(f16x2, p)[1]; }
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
 
 // split 4 fp32 into NP bf16 pieces each; out[p] = 4 packed bf16 (8 bytes)
-template <int NP>
-__device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NP]) {
+template <int NP, bool F16 = false>
+__device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NP], int* ovf = nullptr) {
     float a = v.x, b = v.y, c = v.z, d = v.w;
+    if (F16 && ovf) {   // fp16 pieces cannot hold |x| > 65504: flag it instead of silently producing inf
+        const float m = fmaxf(fmaxf(fabsf(a), fabsf(b)), fmaxf(fabsf(c), fabsf(d)));
+        if (!(m <= 65504.f)) *ovf = 1;
+    }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const unsigned p01 = pk_bf16(a, b), p23 = pk_bf16(c, d);
+        const unsigned p01 = Elt<F16>::pk(a, b), p23 = Elt<F16>::pk(c, d);
         out[p].x = p01;
         out[p].y = p23;
         if (p + 1 < NP) {
-            a -= bf_lo(p01);
-            b -= bf_hi(p01);
-            c -= bf_lo(p23);
-            d -= bf_hi(p23);
+            a -= Elt<F16>::lo(p01);
+            b -= Elt<F16>::hi(p01);
+            c -= Elt<F16>::lo(p23);
+            d -= Elt<F16>::hi(p23);
         }
     }
 }
@@ -141,8 +167,9 @@ __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&a
     }
 }
 
-template <int NT, int NP>
+template <int NT, int NP, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
+    typedef typename Elt<F16>::v8 bf16x8;   // (name kept: 8 packed 16-bit pieces, bf16 or fp16)
     constexpr int BROWS = NT * 32;
     constexpr int A_PLANE = SBM * RSB, B_PLANE = BROWS * RSB;
     constexpr int NBL = (BROWS * 4 * NP + 255) / 256;  // 16-byte weight loads per thread per tile
@@ -224,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
     };
     auto split_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) split4<NP>(ra[i], pa[i]);
+        for (int i = 0; i < 4; ++i) split4<NP, F16>(ra[i], pa[i], p.ovf);
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -251,13 +278,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
     auto mfma_group = [&](const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], f32x16& c) {
         // smallest terms first
         if (NP == 3) {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+            c = Elt<F16>::mfma(a[2], b[0], c);
+            c = Elt<F16>::mfma(a[0], b[2], c);
+            c = Elt<F16>::mfma(a[1], b[1], c);
         }
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+        c = Elt<F16>::mfma(a[1], b[0], c);
+        c = Elt<F16>::mfma(a[0], b[1], c);
+        c = Elt<F16>::mfma(a[0], b[0], c);
     };
 
     // one k-step (16 k) of the staged tile: fragments of group j+1 are read before the MFMAs of group j
@@ -318,11 +345,12 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
 // fragment straight from global memory (2 x 16 B per k-step), splits it into bf16 pieces in registers and feeds the MFMA.
 // Only the weight tile (shared by the four waves) is staged through LDS.  This removes 24 KB of LDS writes and 24 KB of LDS
 // reads per block tile (LDS was 42 % busy with 30 % of that in bank conflicts in the staged kernel, PMC).
-template <int NP>
-__device__ __forceinline__ void split8(f32x4 lo, f32x4 hi, bf16x8 (&out)[NP]) {
+template <int NP, bool F16>
+__device__ __forceinline__ void split8(f32x4 lo, f32x4 hi, typename Elt<F16>::v8 (&out)[NP], int* ovf) {
+    typedef typename Elt<F16>::v8 bf16x8;
     u32x2 pl[NP], ph[NP];
-    split4<NP>(lo, pl);
-    split4<NP>(hi, ph);
+    split4<NP, F16>(lo, pl, ovf);
+    split4<NP, F16>(hi, ph, ovf);
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
         u32x4 v;
@@ -331,8 +359,9 @@ __device__ __forceinline__ void split8(f32x4 lo, f32x4 hi, bf16x8 (&out)[NP]) {
     }
 }
 
-template <int NT, int NP>
+template <int NT, int NP, bool F16>
 __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
+    typedef typename Elt<F16>::v8 bf16x8;
     constexpr int BROWS = NT * 32;
     constexpr int B_PLANE = BROWS * RSB;
     constexpr int NBL = (BROWS * 4 * NP + 255) / 256;
@@ -417,13 +446,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
     const unsigned char* b_frag = Bs + lrow * RSB + half * 16;
     auto mfma_group = [&](const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], f32x16& c) {
         if (NP == 3) {
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
+            c = Elt<F16>::mfma(a[2], b[0], c);
+            c = Elt<F16>::mfma(a[0], b[2], c);
+            c = Elt<F16>::mfma(a[1], b[1], c);
         }
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
+        c = Elt<F16>::mfma(a[1], b[0], c);
+        c = Elt<F16>::mfma(a[0], b[1], c);
+        c = Elt<F16>::mfma(a[0], b[0], c);
     };
 
     const int KT = p.ks * p.ks * p.cchunks;
@@ -433,8 +462,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
     bf16x8 af[2][NP];   // A fragments of the current tile (both k-steps), in registers
     for (int kt = 0; kt < KT; ++kt) {
         // the held registers are tile kt: split A into pieces, publish B through LDS
-        split8<NP>(ra[0], ra[1], af[0]);
-        split8<NP>(ra[2], ra[3], af[1]);
+        split8<NP, F16>(ra[0], ra[1], af[0], p.ovf);
+        split8<NP, F16>(ra[2], ra[3], af[1], p.ovf);
         __syncthreads();   // every wave finished reading the previous B tile
 #pragma unroll
         for (int i = 0; i < NBL; ++i)
@@ -477,21 +506,29 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
 }
 
 // w (fp32, [rows][K], K contiguous) -> planes[NP][rows][K] bf16, w = sum of the planes up to 2^-24 relative
-__global__ void split_weights_kernel(const float* __restrict__ w, int64_t n, int np, unsigned short* __restrict__ planes) {
+__global__ void split_weights_kernel(const float* __restrict__ w, int64_t n, int np, int f16, unsigned short* __restrict__ planes,
+                                     int* ovf) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         float r = w[i];
+        if (f16 && ovf && !(fabsf(r) <= 65504.f)) *ovf = 1;
         for (int q = 0; q < np; ++q) {
-            const __bf16 b = (__bf16)r;
-            planes[(int64_t)q * n + i] = __builtin_bit_cast(unsigned short, b);
-            r -= (float)b;
+            if (f16) {
+                const _Float16 b = (_Float16)r;
+                planes[(int64_t)q * n + i] = __builtin_bit_cast(unsigned short, b);
+                r -= (float)b;
+            } else {
+                const __bf16 b = (__bf16)r;
+                planes[(int64_t)q * n + i] = __builtin_bit_cast(unsigned short, b);
+                r -= (float)b;
+            }
         }
     }
 }
 
-void split_weights(const float* w, int64_t n, int np, void* planes, hipStream_t s) {
+void split_weights(const float* w, int64_t n, int np, void* planes, hipStream_t s, bool f16, int* ovf) {
     if (!n) return;
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)), dim3(256), 0, s, w, n, np,
-                       (unsigned short*)planes);
+                       f16 ? 1 : 0, (unsigned short*)planes, ovf);
     check_launch("split_weights");
 }
 
@@ -503,26 +540,26 @@ bool conv2d_split_eligible(const ConvArgs& a) {
     return xb < 0xFFFFFF00ll && wb < 0xFFFFFF00ll;
 }
 
-template <int NP>
+template <int NP, bool F16>
 static void launch_split(const SplitP& p, int nt, hipStream_t s, bool ad) {
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
     if (ad) {
         switch (nt) {
-            case 1: hipLaunchKernelGGL((conv_split_ad_kernel<1, NP>), grid, dim3(256), 0, s, p); break;
-            case 2: hipLaunchKernelGGL((conv_split_ad_kernel<2, NP>), grid, dim3(256), 0, s, p); break;
-            case 3: hipLaunchKernelGGL((conv_split_ad_kernel<3, NP>), grid, dim3(256), 0, s, p); break;
-            case 4: hipLaunchKernelGGL((conv_split_ad_kernel<4, NP>), grid, dim3(256), 0, s, p); break;
-            default: hipLaunchKernelGGL((conv_split_ad_kernel<5, NP>), grid, dim3(256), 0, s, p); break;
+            case 1: hipLaunchKernelGGL((conv_split_ad_kernel<1, NP, F16>), grid, dim3(256), 0, s, p); break;
+            case 2: hipLaunchKernelGGL((conv_split_ad_kernel<2, NP, F16>), grid, dim3(256), 0, s, p); break;
+            case 3: hipLaunchKernelGGL((conv_split_ad_kernel<3, NP, F16>), grid, dim3(256), 0, s, p); break;
+            case 4: hipLaunchKernelGGL((conv_split_ad_kernel<4, NP, F16>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((conv_split_ad_kernel<5, NP, F16>), grid, dim3(256), 0, s, p); break;
         }
         check_launch("conv_split_ad");
         return;
     }
     switch (nt) {
-        case 1: hipLaunchKernelGGL((conv_split_kernel<1, NP>), grid, dim3(256), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((conv_split_kernel<2, NP>), grid, dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((conv_split_kernel<3, NP>), grid, dim3(256), 0, s, p); break;
-        case 4: hipLaunchKernelGGL((conv_split_kernel<4, NP>), grid, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL((conv_split_kernel<5, NP>), grid, dim3(256), 0, s, p); break;
+        case 1: hipLaunchKernelGGL((conv_split_kernel<1, NP, F16>), grid, dim3(256), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_split_kernel<2, NP, F16>), grid, dim3(256), 0, s, p); break;
+        case 3: hipLaunchKernelGGL((conv_split_kernel<3, NP, F16>), grid, dim3(256), 0, s, p); break;
+        case 4: hipLaunchKernelGGL((conv_split_kernel<4, NP, F16>), grid, dim3(256), 0, s, p); break;
+        default: hipLaunchKernelGGL((conv_split_kernel<5, NP, F16>), grid, dim3(256), 0, s, p); break;
     }
     check_launch("conv_split");
 }
@@ -543,17 +580,20 @@ void conv2d_split(const ConvArgs& a, int nt, hipStream_t s) {
     p.cchunks = a.Cin / SBK;
     p.tiles_m = cdiv(p.M, SBM);
     p.tiles_n = cdiv(a.Cout, nt * 32);
-    const int np = a.precision == PREC_BF16X3 ? 2 : 3;
+    const int np = a.precision == PREC_BF16X6 ? 3 : 2;
     p.x_bytes = (unsigned)(((int64_t)(a.N - 1) * p.x_bs + (int64_t)a.H * a.W * a.Cin) * 4);
     p.w_plane_bytes = (unsigned)((int64_t)a.Cout * p.Ktot * 2);
+    p.ovf = a.ovf;
     p.w_bytes = p.w_plane_bytes * 3u;   // planes are always stored 3 deep; bf16x3 reads the first two
     // A-direct pays for the 3-piece mode on the large layers (+6 % on the 256^2/128^2/64^2 convs); the 2-piece mode and
     // the small-M layers are faster with both operands staged (tools/bench_conv.py 11 31 10 30)
     const bool ad = a.variant == 30 || (a.variant != 31 && np == 3 && (int64_t)p.tiles_m * p.tiles_n >= 512);
-    if (np == 2)
-        launch_split<2>(p, nt, s, ad);
+    if (a.precision == PREC_F16X3)
+        launch_split<2, true>(p, nt, s, ad);
+    else if (np == 2)
+        launch_split<2, false>(p, nt, s, ad);
     else
-        launch_split<3>(p, nt, s, ad);
+        launch_split<3, false>(p, nt, s, ad);
 }
 
 }  // namespace dsd

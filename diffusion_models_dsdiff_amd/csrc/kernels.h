@@ -23,11 +23,12 @@ struct ConvArgs {
     int variant = -1;           // kernel variant override (-1 = default / env DSD_CONV_VARIANT)
     int precision = 0;          // PREC_F32 | PREC_BF16X3 | PREC_BF16X6 (conv_split.hip)
     const void* w_split = nullptr;  // [3][Cout][ks*ks*Cin] bf16 pieces of w (needed for the split precisions)
+    int* ovf = nullptr;             // device flag set by the f16x3 kernels when an operand exceeds the fp16 range
 };
-enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16X6 = 2 };
+enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16X6 = 2, PREC_F16X3 = 3 };
 void conv2d(ConvArgs a, hipStream_t s);
 // conv_split.hip: fp32 operands as sums of bf16 pieces on the bf16 matrix cores
-void split_weights(const float* w, int64_t n, int np, void* planes, hipStream_t s);
+void split_weights(const float* w, int64_t n, int np, void* planes, hipStream_t s, bool f16 = false, int* ovf = nullptr);
 bool conv2d_split_eligible(const ConvArgs& a);
 void conv2d_split(const ConvArgs& a, int nt, hipStream_t s);
 double conv2d_flops(const ConvArgs& a);

@@ -373,12 +373,15 @@ void dsd::net_set_param(dsd_handle* h, const char* name, const float* src, const
         if (!src_is_device) DSD_HIP(hipStreamSynchronize(s));
     }
     p.set = true;
-    auto sp = h->wsplit.find(p.name.size() > 7 ? p.name.substr(0, p.name.size() - 7) : p.name);   // "<conv>.weight" -> "<conv>"
-    if (sp != h->wsplit.end()) {
-        DSD_HIP(hipDeviceSynchronize());
-        (void)hipFree(sp->second);
-        h->wsplit.erase(sp);
-        h->plan.valid = false;
+    const std::string conv_name = p.name.size() > 7 ? p.name.substr(0, p.name.size() - 7) : p.name;   // "<conv>.weight" -> "<conv>"
+    for (const std::string& key : {conv_name, conv_name + "#f16"}) {
+        auto sp = h->wsplit.find(key);
+        if (sp != h->wsplit.end()) {
+            DSD_HIP(hipDeviceSynchronize());
+            (void)hipFree(sp->second);
+            h->wsplit.erase(sp);
+            h->plan.valid = false;
+        }
     }
 }
 
@@ -390,6 +393,7 @@ void dsd::net_free(dsd_handle* h) {
     if (h->mout) (void)hipFree(h->mout);
     if (h->zplane) (void)hipFree(h->zplane);
     if (h->freqs) (void)hipFree(h->freqs);
+    if (h->ovf) (void)hipFree(h->ovf);
     for (auto& kv : h->wsplit) (void)hipFree(kv.second);
     h->wsplit.clear();
     for (auto e : h->ev) (void)hipEventDestroy(e);
@@ -459,16 +463,23 @@ struct Builder {
         if (!to_out) y = alloc(x.n, OH, OW, cout);
         if (res) DSD_CHECK(res->n == x.n && res->h == OH && res->w == OW && res->c == cout, "conv %s: residual shape mismatch", name.c_str());
         if (hd->precision != PREC_F32 && x.c % 32 == 0 && plane < 0) {   // split-bf16 arithmetic: pieces of the (packed) weight
-            auto it = hd->wsplit.find(name);
+            const bool f16 = hd->precision == PREC_F16X3;
+            const std::string key = f16 ? name + "#f16" : name;
+            auto it = hd->wsplit.find(key);
             if (it == hd->wsplit.end()) {
                 void* planes = nullptr;
                 DSD_HIP(hipMalloc(&planes, (size_t)pw.numel * 2 * 3));
-                split_weights(a.w, pw.numel, 3, planes, nullptr);
+                if (f16 && !hd->ovf) {
+                    DSD_HIP(hipMalloc((void**)&hd->ovf, sizeof(int)));
+                    DSD_HIP(hipMemset(hd->ovf, 0, sizeof(int)));
+                }
+                split_weights(a.w, pw.numel, 3, planes, nullptr, f16, hd->ovf);
                 DSD_HIP(hipStreamSynchronize(nullptr));
-                it = hd->wsplit.emplace(name, planes).first;
+                it = hd->wsplit.emplace(key, planes).first;
             }
             a.w_split = it->second;
             a.precision = hd->precision;
+            a.ovf = f16 ? hd->ovf : nullptr;
         }
         const size_t xoff = x.off, yoff = y.off, roff = res ? res->off : 0;
         const bool has_res = res != nullptr;
@@ -1112,4 +1123,15 @@ void dsd::net_run(dsd_handle* h, hipStream_t s) {
         h->prof_calls[k] += 1;
     }
     h->prof_runs += 1;
+}
+
+void dsd::net_check_overflow(dsd_handle* h, hipStream_t s) {
+    if (h->precision != PREC_F16X3 || !h->ovf) return;
+    int flag = 0;
+    DSD_HIP(hipMemcpyAsync(&flag, h->ovf, sizeof(int), hipMemcpyDeviceToHost, s));
+    DSD_HIP(hipStreamSynchronize(s));
+    if (flag) {
+        DSD_HIP(hipMemsetAsync(h->ovf, 0, sizeof(int), s));
+        fail("f16x3: a convolution operand exceeded the fp16 range (|x| > 65504); the result is invalid - use bf16x6 or f32");
+    }
 }

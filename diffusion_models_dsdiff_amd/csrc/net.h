@@ -102,6 +102,7 @@ struct dsd_handle {
     // slice (same input, same timestep for every slice of the batch -> same result).  Off by default.
     int share_zero_streams = 0;
     std::unordered_map<std::string, void*> wsplit;   // parameter name -> [3][numel] bf16 planes
+    int* ovf = nullptr;                              // device flag: fp16 range exceeded in f16x3 mode
     // per-kernel profiling (dsd_profile_*): hipEvents around every op of the plan on the caller's stream
     bool profiling = false;
     std::vector<hipEvent_t> ev;
@@ -122,5 +123,7 @@ void net_set_param(dsd_handle* h, const char* name, const float* src, const int6
 void net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int want_feats, int aux_len, int aux_len2,
               int share = 0);
 void net_run(dsd_handle* h, hipStream_t s);
+// f16x3 only: synchronises the stream and throws if an operand left the fp16 range during the work enqueued so far
+void net_check_overflow(dsd_handle* h, hipStream_t s);
 void net_free(dsd_handle* h);
 }  // namespace dsd

@@ -19,7 +19,7 @@ def to_nchw(x: torch.Tensor) -> torch.Tensor:
     return x.permute(0, 3, 1, 2).contiguous()
 
 
-PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
 
 
 STRUCTURES = {"auto": 0, "adirect": 16, "staged": 32}

@@ -83,9 +83,12 @@ int dsd_set_timestep_freqs(dsd_handle* h, const float* freqs_host, int n);
  * chain); DSD_PREC_BF16X6 = every fp32 operand split exactly into three bf16 pieces, six bf16 MFMA products with fp32
  * accumulation (drops only terms <= 2^-24: fp32-grade, ~1e-6 on the network output); DSD_PREC_BF16X3 = two pieces, three
  * products (~1.5e-5 on the network output, still inside the 1e-4 bar of the sampled image).
+ * DSD_PREC_F16X3 = two fp16 pieces (11 + 11 bits), three products: ~1.4x the fp32 kernel's error at 1.5x the speed of
+ * bf16x6, but fp16's range: if a conv operand exceeds 65504 the call FAILS (device flag, checked with one stream
+ * synchronisation at the end of dsd_forward / dsd_sample) instead of returning inf/NaN.
  * Default: DSD_PREC_BF16X6 (all parity tests hold at the fp32 tolerances); shapes the split kernel cannot take
  * (Cin % 32 != 0, operands >= 4 GiB) use the fp32 kernels in every mode. */
-enum { DSD_PREC_F32 = 0, DSD_PREC_BF16X3 = 1, DSD_PREC_BF16X6 = 2 };
+enum { DSD_PREC_F32 = 0, DSD_PREC_BF16X3 = 1, DSD_PREC_BF16X6 = 2, DSD_PREC_F16X3 = 3 };
 int dsd_set_precision(dsd_handle* h, int precision);
 int dsd_get_precision(dsd_handle* h);
 /* dsd_sample only, OFF by default.  In the 2-channel branch (model.py:654-658) the `al` and `l` encoder streams get
@@ -192,7 +195,7 @@ int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float
                        void* stream);
 /* Micro-benchmark of the convolution kernel on random data (library-owned buffers): average ms per launch over
  * `iters` back-to-back launches (hipEvents) and the algorithmic FLOPs of one launch.  variant: -1/0 default fp32
- * kernel, 1 flat-load fp32 kernel, 10 bf16x3, 11 bf16x6 (library's choice of structure), 20/21 both operands staged
+ * kernel, 1 flat-load fp32 kernel, 10 bf16x3, 11 bf16x6, 12 f16x3 (library's choice of structure), 20/21 both operands staged
  * through LDS, 30/31 activations read straight into registers. */
 int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride, int variant, int iters, float* avg_ms,
                      double* flops);

@@ -133,7 +133,7 @@ def test_model_forward_golden(key):
         assert rel_l2(y, yo) < tol
 
 
-@pytest.mark.parametrize("prec,tol", [("f32", 5e-6), ("bf16x6", 5e-6), ("bf16x3", 1e-4)])
+@pytest.mark.parametrize("prec,tol", [("f32", 5e-6), ("bf16x6", 5e-6), ("f16x3", 5e-6), ("bf16x3", 1e-4)])
 def test_model_precision_modes(prec, tol):
     """Every arithmetic mode of the convolutions against the reference fixture (C_in = 4: no degenerate GroupNorm group).
     bf16x6 must hold the fp32 tolerance; bf16x3 only the 1e-4 bar of the north star (measured ~2e-5)."""
@@ -213,7 +213,7 @@ def test_full_config_forward_vs_oracle(full_model):
         t = torch.tensor([731])
         yo, fo = O.unet_forward(cfg, sd, x, t)
         assert float(yo.abs().max()) > 1e-3                              # non-vacuous: zero_module sites re-randomised
-        for prec, tol in (("bf16x6", 1e-5), ("f32", 1e-5), ("bf16x3", 1e-4)):
+        for prec, tol in (("bf16x6", 1e-5), ("f32", 1e-5), ("f16x3", 1e-5), ("bf16x3", 1e-4)):
             m.set_precision(prec)
             y, feats = m(x.cuda(), t.cuda())
             err = rel_l2(y, yo)
@@ -236,7 +236,7 @@ def test_full_config_ddpm_chain_vs_oracle(full_model):
     d = create_gaussian_diffusion(steps=1000, parameterization="v")
     sched = d._schedule(False, 0.0, True)
     ys = {}
-    for prec in ("bf16x6", "f32", "bf16x3"):
+    for prec in ("bf16x6", "f32", "f16x3", "bf16x3"):
         m.set_precision(prec)
         ys[prec] = run_device_loop(m, sched, x_start.cuda(), cond.cuda(), step_noise=z.cuda(), first_step=1000 - n, n_steps=n)
     m.set_precision("bf16x6")

@@ -62,10 +62,10 @@ CONV_CASES = [
 
 # arithmetic modes of the convolution: fp32 MFMA (exact fmaf chain), bf16x6 (fp32 split into 3 bf16 pieces, 6 products:
 # fp32-grade), bf16x3 (2 pieces, 3 products: ~2^-16 per product).  Tolerances are rel-L2 vs float64.
-PREC_TOL = {"f32": 2e-6, "bf16x6": 2e-6, "bf16x3": 3e-5}
+PREC_TOL = {"f32": 2e-6, "bf16x6": 2e-6, "f16x3": 3e-6, "bf16x3": 3e-5}
 
 
-@pytest.mark.parametrize("prec", ["f32", "bf16x6", "bf16x3"])
+@pytest.mark.parametrize("prec", ["f32", "bf16x6", "f16x3", "bf16x3"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv2d_vs_torch_cpu(ops, case, prec):
     N, H, W, Cin, Cout, ks, stride, ups = case
@@ -80,7 +80,7 @@ def test_conv2d_vs_torch_cpu(ops, case, prec):
 
 
 @pytest.mark.parametrize("structure", ["adirect", "staged"])
-@pytest.mark.parametrize("prec", ["bf16x6", "bf16x3"])
+@pytest.mark.parametrize("prec", ["bf16x6", "f16x3", "bf16x3"])
 def test_conv2d_split_structures(ops, prec, structure):
     """Both kernel structures of the split-bf16 convolution (the library picks per shape) on every eligible case,
     incl. the epilogue fusions, stride 2, folded upsample and ragged M / N tiles."""
@@ -117,6 +117,15 @@ def test_conv2d_split_extreme_magnitudes(ops):
             y = ops.conv2d(cu(ops.to_nhwc(x)), cu(w), None, precision=prec, structure=structure)
             assert bool(torch.isfinite(y).all())
             assert rel_l2(ops.to_nchw(y), ref) < PREC_TOL[prec], (prec, structure)
+    # fp16 pieces do NOT have that range: the call must fail loudly instead of returning inf / NaN
+    from diffusion_models_dsdiff_amd import _lib
+    for structure in ("staged", "adirect"):
+        with pytest.raises(_lib.DsdError, match="fp16 range"):
+            ops.conv2d(cu(ops.to_nhwc(x)), cu(w), None, precision="f16x3", structure=structure)
+    small = x.clone()
+    small[:, 16:32] *= 1e-18                      # back inside the range: fine again (tiny values lose nothing that matters)
+    y = ops.conv2d(cu(ops.to_nhwc(small)), cu(w), None, precision="f16x3")
+    assert rel_l2(ops.to_nchw(y), F.conv2d(small.double(), w.double(), None, padding=1)) < PREC_TOL["f16x3"]
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16x6"])
