@@ -65,17 +65,31 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[k][e] = q[k][e] = 0.0;
     const float* base = x + (int64_t)n * HW * C;
-    for (int p = p0 + row; p < p1; p += rpi) {
+    auto accum = [&](int k, const float4 v) {
+        const double a = v.x, b = v.y, c = v.z, d = v.w;
+        s[k][0] += a; q[k][0] = fma(a, a, q[k][0]);
+        s[k][1] += b; q[k][1] = fma(b, b, q[k][1]);
+        s[k][2] += c; q[k][2] = fma(c, c, q[k][2]);
+        s[k][3] += d; q[k][3] = fma(d, d, q[k][3]);
+    };
+    // 4 pixel rows per trip: 4*K independent 16-byte loads in flight per thread before the fp64 accumulation
+    int p = p0 + row;
+    for (; p + 3 * rpi < p1; p += 4 * rpi) {
+        float4 v[4][K];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < K; ++k)
+                v[u][k] = reinterpret_cast<const float4*>(base + (int64_t)(p + u * rpi) * C)[col0 + k * colsk];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int k = 0; k < K; ++k) accum(k, v[u][k]);
+    }
+    for (; p < p1; p += rpi) {
         const float4* rp = reinterpret_cast<const float4*>(base + (int64_t)p * C);
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float4 v = rp[col0 + k * colsk];
-            const double a = v.x, b = v.y, c = v.z, d = v.w;
-            s[k][0] += a; q[k][0] = fma(a, a, q[k][0]);
-            s[k][1] += b; q[k][1] = fma(b, b, q[k][1]);
-            s[k][2] += c; q[k][2] = fma(c, c, q[k][2]);
-            s[k][3] += d; q[k][3] = fma(d, d, q[k][3]);
-        }
+        for (int k = 0; k < K; ++k) accum(k, rp[col0 + k * colsk]);
     }
 #pragma unroll
     for (int k = 0; k < K; ++k)
@@ -177,10 +191,9 @@ template <int ACT>
 __global__ __launch_bounds__(256) void affine_act_kernel(const float4* __restrict__ x, int64_t total4, int cols,
                                                          int64_t per_sample4, const float4* __restrict__ scale,
                                                          const float4* __restrict__ shift, float4* __restrict__ y) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    auto one = [&](int64_t i, const float4 v) {
         const int n = (int)(i / per_sample4);
         const int c4 = (int)(i % cols);
-        const float4 v = x[i];
         const float4 sc = scale[(int64_t)n * cols + c4];
         const float4 sh = shift[(int64_t)n * cols + c4];
         float4 o;
@@ -195,7 +208,17 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const float4* __restric
             o.w = silu_f(o.w);
         }
         y[i] = o;
+    };
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < total4; i += 4 * stride) {   // 4 independent 16-byte loads in flight per thread
+        const float4 v0 = x[i], v1 = x[i + stride], v2 = x[i + 2 * stride], v3 = x[i + 3 * stride];
+        one(i, v0);
+        one(i + stride, v1);
+        one(i + 2 * stride, v2);
+        one(i + 3 * stride, v3);
     }
+    for (; i < total4; i += stride) one(i, x[i]);
 }
 
 void affine_act(const float* x, int N, int HW, int C, const float* scale, const float* shift, int act, float* y,
