@@ -85,7 +85,8 @@ int dsd_set_timestep_freqs(dsd_handle* h, const float* freqs_host, int n);
  * products (~1.5e-5 on the network output, still inside the 1e-4 bar of the sampled image).
  * DSD_PREC_F16X3 = two fp16 pieces (11 + 11 bits), three products: ~1.4x the fp32 kernel's error at 1.5x the speed of
  * bf16x6, but fp16's range: if a conv operand exceeds 65504 the call FAILS (device flag, checked with one stream
- * synchronisation at the end of dsd_forward / dsd_sample) instead of returning inf/NaN.
+ * synchronisation at the end of dsd_forward / dsd_sample) instead of returning inf/NaN, and operands that are uniformly
+ * tiny lose accuracy (absolute floor 3e-8: |x|~1e-3 -> 2e-5 relative).  Meant for GroupNorm-normalised activations.
  * Default: DSD_PREC_BF16X6 (all parity tests hold at the fp32 tolerances); shapes the split kernel cannot take
  * (Cin % 32 != 0, operands >= 4 GiB) use the fp32 kernels in every mode. */
 enum { DSD_PREC_F32 = 0, DSD_PREC_BF16X3 = 1, DSD_PREC_BF16X6 = 2, DSD_PREC_F16X3 = 3 };
