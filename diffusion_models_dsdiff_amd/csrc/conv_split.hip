@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
 
     // ---- A staging: thread -> (row = tid>>3 (+32 i), 4 consecutive k = 4*(tid&7)), fp32 in HBM, split on the fly
     const int col4 = tid & 7;
-    const int srow = tid >> 3;
+    // 16 consecutive lanes (one ds_write_b64 bank group) cover rows r and r+4 (see the B mapping below): conflict-free
+    const int srow = ((tid >> 6) << 3) + (((tid >> 3) & 1) << 2) + ((tid >> 4) & 3);
     int a_h[4], a_w[4];
     unsigned a_nb[4];
     bool a_ok[4];
@@ -233,7 +234,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
         const int q = tid + 256 * i;
         const int piece = q / (BROWS * 4);
         const int rem = q - piece * (BROWS * 4);
-        const int row = rem >> 2, ch = rem & 3;
+        // 8 consecutive lanes (one ds_write_b128 bank group) write rows r and r+4: with the 80-byte row stride their two
+        // 64-byte segments are 320 B = 64 (mod 128) apart, i.e. all 32 banks exactly once (rows r, r+1 overlap on 4 banks)
+        const int ch = rem & 3;
+        const int row = (rem >> 5) * 8 + ((rem >> 3) & 3) + 4 * ((rem >> 2) & 1);
         const int n = n0 + row;
         const bool ok = piece < NP && n < p.Cout;
         b_voff[i] = ok ? (unsigned)piece * p.w_plane_bytes + ((unsigned)n * (unsigned)p.Ktot) * 2u + (unsigned)(ch * 16) : OOB;
@@ -423,7 +427,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
         const int q = tid + 256 * i;
         const int piece = q / (BROWS * 4);
         const int rem = q - piece * (BROWS * 4);
-        const int row = rem >> 2, ch = rem & 3;
+        // 8 consecutive lanes (one ds_write_b128 bank group) write rows r and r+4: with the 80-byte row stride their two
+        // 64-byte segments are 320 B = 64 (mod 128) apart, i.e. all 32 banks exactly once (rows r, r+1 overlap on 4 banks)
+        const int ch = rem & 3;
+        const int row = (rem >> 5) * 8 + ((rem >> 3) & 3) + 4 * ((rem >> 2) & 1);
         const int n = n0 + row;
         const bool ok = piece < NP && n < p.Cout;
         b_voff[i] = ok ? (unsigned)piece * p.w_plane_bytes + ((unsigned)n * (unsigned)p.Ktot) * 2u + (unsigned)(ch * 16) : OOB;
