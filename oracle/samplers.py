@@ -153,12 +153,20 @@ class DiffusionB:
 
     @torch.no_grad()
     def ddim_sample(self, model, S_steps, x_T, noise, cond=None, eta=0.0, clip_denoised=True,
-                    ddim_discretize="uniform"):
-        """DDIMSampler.make_schedule/ddim_sampling/p_sample_ddim ddim.py:25-55,128-261 (ddim_use_original_steps=False)."""
+                    ddim_discretize="uniform", use_original_steps=False):
+        """DDIMSampler.make_schedule/ddim_sampling/p_sample_ddim ddim.py:25-55,128-261."""
         ac = self.tab["alphas_cumprod"].numpy()
-        ts = S.make_ddim_timesteps(ddim_discretize, S_steps, self.num_timesteps)
-        sig, a, a_prev = S.make_ddim_sampling_parameters(ac, ts, eta)
-        sqrt_1ma = np.sqrt(1. - a)
+        if use_original_steps:                                            # ddim.py:52-55,145-153,230-233: index == t
+            ts = np.arange(self.num_timesteps)
+            acp = self.tab["alphas_cumprod_prev"]
+            act = self.tab["alphas_cumprod"]
+            sig = (eta * torch.sqrt((1 - acp) / (1 - act) * (1 - act / acp))).numpy()
+            a, a_prev = ac, acp.numpy()
+            sqrt_1ma = self.tab["sqrt_one_minus_alphas_cumprod"].numpy()
+        else:
+            ts = S.make_ddim_timesteps(ddim_discretize, S_steps, self.num_timesteps)
+            sig, a, a_prev = S.make_ddim_sampling_parameters(ac, ts, eta)
+            sqrt_1ma = np.sqrt(1. - a)
         img = x_T
         b = x_T.shape[0]
         total = ts.shape[0]

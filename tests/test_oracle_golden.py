@@ -234,3 +234,29 @@ def test_loop_ddpm_1000_steps():
     d = samplers.DiffusionA(steps=1000, timestep_respacing="", rescale_timesteps=False, parameterization="v")
     z = randn((1000,) + shape, int(gl["A_ddpm_1000_noise_seed"]))
     assert rel_l2(d.p_sample_loop(model, xT, z, [cond]), gl["A_ddpm_1000_y"]) < TOL_LOOP
+
+
+def test_loops_more_branches():
+    """eps / x0 prediction, FIXED_SMALL, clip off, DDIM eta 0.5, 'ddimN' striding; family-B DDIM with eps and with
+    ddim_use_original_steps (tests/golden/loops2.npz, produced by the reference's own loops)."""
+    gl2 = golden("loops2")
+    gl, model, shape, cond, xT = _loop_setup()
+    A = samplers.DiffusionA
+    cases = [("A_eps_ddpm_20", A(steps=1000, timestep_respacing="20", rescale_timesteps=True), "ddpm", {}),
+             ("A_eps_small_ddpm_20", A(steps=1000, timestep_respacing="20", rescale_timesteps=True, sigma_small=True), "ddpm", {}),
+             ("A_x0_ddpm_20", A(steps=1000, timestep_respacing="20", rescale_timesteps=True, predict_xstart=True), "ddpm", {}),
+             ("A_eps_ddim_20_eta05", A(steps=1000, timestep_respacing="20", rescale_timesteps=True), "ddim", {"eta": 0.5}),
+             ("A_x0_ddim_ddim25", A(steps=1000, timestep_respacing="ddim25", predict_xstart=True), "ddim", {"eta": 0.0}),
+             ("A_v_noclip_ddpm_20", A(steps=1000, timestep_respacing="20", rescale_timesteps=True, parameterization="v"), "ddpm",
+              {"clip_denoised": False})]
+    for key, d, kind, kw in cases:
+        z = randn((d.num_timesteps,) + shape, int(gl2[key + "_noise_seed"]))
+        fn = d.p_sample_loop if kind == "ddpm" else d.ddim_sample_loop
+        assert rel_l2(fn(model, xT, z, [cond], **kw), gl2[key + "_y"]) < TOL_LOOP, key
+    for key, param, S_, orig, eta in (("B_eps_ddim_10", "eps", 10, False, 0.0), ("B_v_ddim_orig50_eta1", "v", 10, True, 1.0),
+                                      ("B_eps_ddim_orig50", "eps", 10, True, 0.0)):
+        d = samplers.DiffusionB(timesteps=50, parameterization=param)
+        n = 50 if orig else S_
+        z = randn((n,) + shape, int(gl2[key + "_noise_seed"]))
+        y = d.ddim_sample(model, S_, xT, z, [cond], eta=eta, use_original_steps=orig)
+        assert rel_l2(y, gl2[key + "_y"]) < TOL_LOOP, key

@@ -152,3 +152,34 @@ def test_share_zero_streams_is_bit_identical(env):
         assert torch.equal(a, b), prec
         assert f1 < 0.85 * f0
     unet.set_precision("bf16x6")
+
+
+def test_more_sampler_branches(env):
+    """eps / x0 prediction, FIXED_SMALL variance, clip off, DDIM eta 0.5, 'ddimN' striding (family A); eps-parameterised and
+    ddim_use_original_steps DDIM (family B) — fixtures from the reference's own loops (tests/golden/loops2.npz)."""
+    from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
+    from diffusion_models_dsdiff_amd.trainers.trainer_ddpm import DDPMModel
+    from diffusion_models_dsdiff_amd.ldm.models.diffusion.ddim import DDIMSampler
+    gl, wrap, cond, xT, _ = env
+    gl2 = golden("loops2")
+    mk = create_gaussian_diffusion
+    cases = [("A_eps_ddpm_20", mk(steps=1000, timestep_respacing="20", rescale_timesteps=True), "p_sample_loop", {}),
+             ("A_eps_small_ddpm_20", mk(steps=1000, timestep_respacing="20", rescale_timesteps=True, sigma_small=True), "p_sample_loop", {}),
+             ("A_x0_ddpm_20", mk(steps=1000, timestep_respacing="20", rescale_timesteps=True, predict_xstart=True), "p_sample_loop", {}),
+             ("A_eps_ddim_20_eta05", mk(steps=1000, timestep_respacing="20", rescale_timesteps=True), "ddim_sample_loop", {"eta": 0.5}),
+             ("A_x0_ddim_ddim25", mk(steps=1000, timestep_respacing="ddim25", predict_xstart=True), "ddim_sample_loop", {"eta": 0.0}),
+             ("A_v_noclip_ddpm_20", mk(steps=1000, timestep_respacing="20", rescale_timesteps=True, parameterization="v"),
+              "p_sample_loop", {"clip_denoised": False})]
+    for key, d, fn, kw in cases:
+        z = randn((d.num_timesteps,) + SHAPE, int(gl2[key + "_noise_seed"])).cuda()
+        y = getattr(d, fn)(wrap, SHAPE, noise=xT, model_kwargs=dict(c_concat=[cond]), step_noise=z, **kw)
+        assert rel_l2(y, gl2[key + "_y"]) < TOL, key
+    for key, param, S_, orig, eta in (("B_eps_ddim_10", "eps", 10, False, 0.0), ("B_v_ddim_orig50_eta1", "v", 10, True, 1.0),
+                                      ("B_eps_ddim_orig50", "eps", 10, True, 0.0)):
+        m = DDPMModel(timesteps=50, parameterization=param).cuda()
+        m.model = wrap
+        n = 50 if orig else S_
+        z = randn((n,) + SHAPE, int(gl2[key + "_noise_seed"])).cuda()
+        y, _ = DDIMSampler(m).sample(S_, 2, SHAPE[1:], dict(c_concat=[cond]), eta=eta, verbose=False, x_T=xT, step_noise=z,
+                                     ddim_use_original_steps=orig)
+        assert rel_l2(y, gl2[key + "_y"]) < TOL, key
