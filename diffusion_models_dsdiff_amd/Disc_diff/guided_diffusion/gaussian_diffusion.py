@@ -181,6 +181,26 @@ class GaussianDiffusion:
         return self._loop(True, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device,
                           progress, eta, step_noise, seed)
 
+    def dpm_solver_sample_loop(self, model, shape, clip_denoised=None, model_kwargs=None, noise=None, device=None):
+        """:467-522 — DPM-Solver++ multistep order 2 over this (possibly respaced) schedule: ``num_timesteps`` network
+        evaluations, logSNR spacing, dynamic thresholding, no lower-order final step.  As in the reference the network
+        receives the solver's continuous model time (no timestep_map / rescale) and ``clip_denoised`` is unused.
+        ``noise`` (x_T) is an extension for reproducible runs; the reference draws it itself (:470)."""
+        from .sampler import NoiseScheduleVP, model_wrapper, DPM_Solver
+        if device is None:
+            device = next(model.parameters()).device if hasattr(model, "parameters") else th.device("cuda")
+            if th.device(device).type != "cuda":
+                device = th.device("cuda")
+        x = (noise if noise is not None else th.randn(*shape, device=device)).to(device)
+        thresholding, denoise = True, False
+        noise_schedule = NoiseScheduleVP(schedule="discrete", betas=th.from_numpy(self.betas).float())
+        model_fn_continuous = model_wrapper(model, noise_schedule, model_type="noise", model_kwargs=model_kwargs or {})
+        dpm_solver = DPM_Solver(model_fn_continuous, noise_schedule, algorithm_type="dpmsolver++",
+                                correcting_x0_fn="dynamic_thresholding" if thresholding else None)
+        return dpm_solver.sample(x, steps=(self.num_timesteps - 1 if denoise else self.num_timesteps), order=2,
+                                 skip_type="logSNR", method="multistep", lower_order_final=False,
+                                 denoise_to_zero=denoise, solver_type="dpmsolver")
+
     def _progressive(self, ddim, model, shape, noise, clip_denoised, model_kwargs, device, eta):
         model_kwargs = model_kwargs or {}
         sched = self._schedule(ddim, eta, clip_denoised)

@@ -25,7 +25,7 @@ PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
 EXPORTS = [
     "dsd_last_error", "dsd_device_info", "dsd_create", "dsd_destroy", "dsd_param_count", "dsd_param_info",
     "dsd_set_param", "dsd_set_timestep_freqs", "dsd_set_precision", "dsd_get_precision", "dsd_set_share_zero_streams", "dsd_params_ready", "dsd_plan", "dsd_workspace_bytes", "dsd_plan_launches", "dsd_plan_flops",
-    "dsd_profile_enable", "dsd_profile_count", "dsd_profile_get", "dsd_forward", "dsd_sample", "dsd_op_sampler_update", "dsd_block_create", "dsd_block_forward", "dsd_bench_conv2d", "dsd_op_conv2d", "dsd_op_conv2d_prec",
+    "dsd_profile_enable", "dsd_profile_count", "dsd_profile_get", "dsd_forward", "dsd_sample", "dsd_op_sampler_update", "dsd_sample_dpm", "dsd_op_dpm_step", "dsd_op_dpm_threshold", "dsd_block_create", "dsd_block_forward", "dsd_bench_conv2d", "dsd_op_conv2d", "dsd_op_conv2d_prec",
     "dsd_op_group_norm", "dsd_op_qkv_attention", "dsd_op_timestep_embedding", "dsd_op_linear", "dsd_op_philox_normal",
 ]
 
@@ -46,6 +46,14 @@ class DsdSchedule(C.Structure):
         ("steps", C.c_int32), ("mode", C.c_int32), ("pred", C.c_int32), ("learned_range", C.c_int32),
         ("clip_denoised", C.c_int32), ("eta", C.c_float), ("coef", C.POINTER(C.c_float)),
         ("t_model", C.POINTER(C.c_float)), ("nonzero", C.POINTER(C.c_int32)),
+    ]
+
+
+class DsdDpmSchedule(C.Structure):
+    _fields_ = [
+        ("steps", C.c_int32), ("pred", C.c_int32), ("data_pred", C.c_int32), ("thresholding", C.c_int32),
+        ("threshold_ratio", C.c_float), ("threshold_max", C.c_float), ("coef", C.POINTER(C.c_float)),
+        ("t_input", C.POINTER(C.c_float)), ("order", C.POINTER(C.c_int32)),
     ]
 
 
@@ -104,6 +112,9 @@ def lib() -> C.CDLL:
     L.dsd_forward.argtypes = [vp, f32p, vp, i32, i32, i32, i32, i32, f32p, C.POINTER(vp), vp]
     L.dsd_sample.argtypes = [vp, C.POINTER(DsdSchedule), f32p, i32, f32p, f32p, C.c_uint64, i32, i32, i32, i32, i32, vp]
     L.dsd_op_sampler_update.argtypes = [C.POINTER(DsdSchedule), i32, f32p, f32p, f32p, C.c_uint64, i32, i32, i32, f32p, vp]
+    L.dsd_sample_dpm.argtypes = [vp, C.POINTER(DsdDpmSchedule), f32p, i32, f32p, i32, i32, i32, vp]
+    L.dsd_op_dpm_step.argtypes = [C.POINTER(DsdDpmSchedule), i32, f32p, i32, f32p, f32p, f32p, i32, i32, i32, vp]
+    L.dsd_op_dpm_threshold.argtypes = [f32p, i32, i32, C.c_float, C.c_float, f32p, f32p, vp]
     L.dsd_block_create.argtypes = [i32, C.POINTER(C.c_int32), i32, i32, C.POINTER(vp)]
     L.dsd_block_forward.argtypes = [vp, f32p, i32, i32, i32, i32, f32p, i32, f32p, i32, f32p, vp]
     L.dsd_op_conv2d.argtypes = [f32p, i32, i32, i32, i32, f32p, f32p, i32, i32, i32, i32, f32p, f32p, f32p, vp]

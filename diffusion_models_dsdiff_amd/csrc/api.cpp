@@ -289,22 +289,8 @@ static void check_schedule(const dsd_schedule* sc) {
     DSD_CHECK(!(sc->learned_range && sc->mode >= DSD_MODE_B_DDPM), "learned-range variance exists only in the guided-diffusion family");
 }
 
-int dsd_sample(dsd_handle* h, const dsd_schedule* sc, const float* cond, int Cc, float* x, const float* noise,
-               uint64_t philox_seed, int B, int H, int W, int first_step, int n_steps, void* stream) {
-    DSD_TRY
-    DSD_CHECK(h && !h->is_block && cond && x, "null argument");
-    check_schedule(sc);
-    DSD_CHECK(Cc == 1 || Cc == 3, "cond must have 1 or 3 channels, got %d", Cc);
-    const int out_ch = h->cfg.out_channels;
-    DSD_CHECK(out_ch == (sc->learned_range ? 2 : 1), "model has %d output channels but the schedule expects %d", out_ch,
-              sc->learned_range ? 2 : 1);
-    set_device(h->device);
-    hipStream_t s = (hipStream_t)stream;
-    const int64_t hw = (int64_t)H * W;
-    net_plan(h, B, Cc + 1, H, W, Cc == 1, 0, 0, 0, (Cc == 1 && B > 1) ? h->share_zero_streams : 0);
-    ensure_buf(&h->tbuf, &h->tbuf_cap, (size_t)B * sizeof(float));
-    ensure_buf(&h->mout, &h->mout_cap, (size_t)B * out_ch * hw * sizeof(float));
-    // DiffusionWrapper 'concat' (ddpm.py:1331-1333) without materialising the cat: streams read planes in place
+// DiffusionWrapper 'concat' (ddpm.py:1331-1333) without materialising the cat: streams read planes in place
+static void bind_sampling_io(dsd_handle* h, float* x, const float* cond, int Cc, int64_t hw, hipStream_t s) {
     h->io.plane[0] = x;
     h->io.plane_bs[0] = hw;
     h->io.plane[1] = cond;
@@ -323,6 +309,24 @@ int dsd_sample(dsd_handle* h, const dsd_schedule* sc, const float* cond, int Cc,
     h->io.t_is_float = 1;
     h->io.out = h->mout;
     h->io.feats = nullptr;
+}
+
+int dsd_sample(dsd_handle* h, const dsd_schedule* sc, const float* cond, int Cc, float* x, const float* noise,
+               uint64_t philox_seed, int B, int H, int W, int first_step, int n_steps, void* stream) {
+    DSD_TRY
+    DSD_CHECK(h && !h->is_block && cond && x, "null argument");
+    check_schedule(sc);
+    DSD_CHECK(Cc == 1 || Cc == 3, "cond must have 1 or 3 channels, got %d", Cc);
+    const int out_ch = h->cfg.out_channels;
+    DSD_CHECK(out_ch == (sc->learned_range ? 2 : 1), "model has %d output channels but the schedule expects %d", out_ch,
+              sc->learned_range ? 2 : 1);
+    set_device(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t hw = (int64_t)H * W;
+    net_plan(h, B, Cc + 1, H, W, Cc == 1, 0, 0, 0, (Cc == 1 && B > 1) ? h->share_zero_streams : 0);
+    ensure_buf(&h->tbuf, &h->tbuf_cap, (size_t)B * sizeof(float));
+    ensure_buf(&h->mout, &h->mout_cap, (size_t)B * out_ch * hw * sizeof(float));
+    bind_sampling_io(h, x, cond, Cc, hw, s);
     const int k0 = first_step < 0 ? 0 : first_step;
     const int k1 = n_steps <= 0 ? sc->steps : std::min(sc->steps, k0 + n_steps);
     for (int k = k0; k < k1; ++k) {
@@ -341,6 +345,78 @@ int dsd_op_sampler_update(const dsd_schedule* sc, int k, const float* model_out,
     check_schedule(sc);
     DSD_CHECK(k >= 0 && k < sc->steps && model_out && x, "bad argument");
     sampler_update(step_coef(sc, k), model_out, x, noise, philox_seed, (uint64_t)k, B, H * W, (hipStream_t)stream, pred_xstart);
+    DSD_CATCH
+}
+
+// ------------------------------------------------------------------------------------------- DPM-Solver(++)
+static void check_dpm_schedule(const dsd_dpm_schedule* sc) {
+    DSD_CHECK(sc && sc->steps > 0 && sc->coef && sc->t_input && sc->order, "bad DPM schedule");
+    DSD_CHECK(sc->pred >= DSD_PRED_EPS && sc->pred <= DSD_PRED_V, "bad pred %d", sc->pred);
+    for (int k = 0; k < sc->steps; ++k) {
+        DSD_CHECK(sc->order[k] >= 0 && sc->order[k] <= 2, "order[%d] = %d: the multistep solver is built for order <= 2", k,
+                  sc->order[k]);
+        DSD_CHECK(!(k == 0 && sc->order[k] == 2), "the first update cannot be second order");
+    }
+    DSD_CHECK(!sc->thresholding || (sc->threshold_ratio >= 0.f && sc->threshold_ratio <= 1.f), "threshold_ratio outside [0,1]");
+}
+
+static DpmCoef dpm_coef(const dsd_dpm_schedule* sc, int k) {
+    const float* c = sc->coef + (size_t)k * DSD_NCOEF;
+    DpmCoef d;
+    d.alpha = c[0]; d.sigma = c[1]; d.cx = c[2]; d.cm = c[3]; d.cd = c[4]; d.ir0 = c[5];
+    d.order = sc->order[k];
+    d.pred = sc->pred;
+    d.data_pred = sc->data_pred || d.order == 0;
+    d.thresh = sc->thresholding;
+    return d;
+}
+
+int dsd_sample_dpm(dsd_handle* h, const dsd_dpm_schedule* sc, const float* cond, int Cc, float* x, int B, int H, int W,
+                   void* stream) {
+    DSD_TRY
+    DSD_CHECK(h && !h->is_block && cond && x, "null argument");
+    check_dpm_schedule(sc);
+    DSD_CHECK(Cc == 1 || Cc == 3, "cond must have 1 or 3 channels, got %d", Cc);
+    const int out_ch = h->cfg.out_channels;
+    DSD_CHECK(out_ch == 1 || out_ch == 2, "model has %d output channels; the solver takes 1 (or 2 with a learned sigma)", out_ch);
+    set_device(h->device);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t hw = (int64_t)H * W;
+    net_plan(h, B, Cc + 1, H, W, Cc == 1, 0, 0, 0, (Cc == 1 && B > 1) ? h->share_zero_streams : 0);
+    ensure_buf(&h->tbuf, &h->tbuf_cap, (size_t)B * sizeof(float));
+    ensure_buf(&h->mout, &h->mout_cap, (size_t)B * out_ch * hw * sizeof(float));
+    ensure_buf(&h->dpm_m, &h->dpm_m_cap, ((size_t)2 * B * hw + B) * sizeof(float));
+    bind_sampling_io(h, x, cond, Cc, hw, s);
+    float* m_cur = h->dpm_m;
+    float* m_prev = h->dpm_m + (size_t)B * hw;
+    float* s_buf = h->dpm_m + (size_t)2 * B * hw;
+    for (int k = 0; k < sc->steps; ++k) {
+        fill_t(h->tbuf, B, sc->t_input[k], s);
+        net_run(h, s);
+        dpm_step(dpm_coef(sc, k), h->mout, out_ch, x, m_cur, m_prev, s_buf, sc->threshold_ratio, sc->threshold_max, B, (int)hw, s);
+        std::swap(m_cur, m_prev);
+    }
+    net_check_overflow(h, s);
+    DSD_CATCH
+}
+
+int dsd_op_dpm_step(const dsd_dpm_schedule* sc, int k, const float* model_out, int Cm, float* x, float* m_cur,
+                    const float* m_prev, int B, int H, int W, void* stream) {
+    DSD_TRY
+    check_dpm_schedule(sc);
+    DSD_CHECK(k >= 0 && k < sc->steps && model_out && x && m_cur && (Cm == 1 || Cm == 2), "bad argument");
+    DSD_CHECK(sc->order[k] < 2 || m_prev, "a second-order update needs m_prev");
+    Tmp sb((size_t)B * sizeof(float));
+    dpm_step(dpm_coef(sc, k), model_out, Cm, x, m_cur, m_prev, sb.as<float>(), sc->threshold_ratio, sc->threshold_max, B, H * W,
+             (hipStream_t)stream);
+    DSD_HIP(hipStreamSynchronize((hipStream_t)stream));
+    DSD_CATCH
+}
+
+int dsd_op_dpm_threshold(const float* x0, int B, int n, float ratio, float max_val, float* y, float* s_out, void* stream) {
+    DSD_TRY
+    DSD_CHECK(x0 && y && s_out && B >= 0 && n >= 1 && ratio >= 0.f && ratio <= 1.f, "bad argument");
+    dpm_threshold(x0, y, s_out, ratio, max_val, B, n, (hipStream_t)stream);
     DSD_CATCH
 }
 

@@ -86,6 +86,17 @@ struct StepCoef {
 // model_out: [B,Cm,HW] (Cm = 1, or 2 with learned_range); x in/out [B,1,HW]; noise [B,1,HW] or null (Philox)
 void sampler_update(const StepCoef& sc, const float* model_out, float* x, const float* noise, uint64_t seed,
                     uint64_t step, int B, int HW, hipStream_t s, float* x0_out = nullptr);
+// DPM-Solver(++) multistep: coefficients of one network evaluation + update (host tables, include/dsdiff.h dsd_dpm_schedule)
+struct DpmCoef {
+    float alpha, sigma;      // marginal alpha_t, sigma_t at the evaluation time
+    float cx, cm, cd, ir0;   // x <- (cx*x - cm*m0) - cd*(ir0*(m0 - m1))
+    int order;               // 0: x <- m0 (denoise to zero), 1, 2
+    int pred;                // DSD_PRED_* of the network
+    int data_pred, thresh;
+};
+void dpm_step(const DpmCoef& c, const float* model_out, int Cm, float* x, float* m_cur, const float* m_prev, float* s_buf,
+              float ratio, float max_val, int B, int HW, hipStream_t s);
+void dpm_threshold(const float* x0, float* y, float* s_buf, float ratio, float max_val, int B, int n, hipStream_t s);
 void philox_normal(float* y, int64_t n, uint64_t seed, uint64_t step, hipStream_t s);
 void fill_t(float* t, int B, float v, hipStream_t s);
 

@@ -392,6 +392,7 @@ void dsd::net_free(dsd_handle* h) {
     if (h->tbuf) (void)hipFree(h->tbuf);
     if (h->mout) (void)hipFree(h->mout);
     if (h->zplane) (void)hipFree(h->zplane);
+    if (h->dpm_m) (void)hipFree(h->dpm_m);
     if (h->freqs) (void)hipFree(h->freqs);
     if (h->ovf) (void)hipFree(h->ovf);
     for (auto& kv : h->wsplit) (void)hipFree(kv.second);

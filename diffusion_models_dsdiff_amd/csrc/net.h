@@ -95,6 +95,7 @@ struct dsd_handle {
     float* tbuf = nullptr;     // [B] timesteps (fp32)
     float* mout = nullptr;     // [B,out_ch,H,W]
     float* zplane = nullptr;   // [H*W] zeros
+    float* dpm_m = nullptr;    // dsd_sample_dpm: m_k, m_{k-1} [B,H*W] each + thresholds [B]
     float* freqs = nullptr;    // [model_channels/2] optional timestep-embedding frequency table (host-supplied)
     // arithmetic mode of the convolutions (PREC_*): bf16 pieces of each conv weight are made lazily at plan time
     int precision = dsd::PREC_BF16X6;
@@ -110,7 +111,7 @@ struct dsd_handle {
     std::vector<int64_t> prof_calls;
     std::vector<std::string> prof_names;
     int prof_runs = 0;
-    size_t tbuf_cap = 0, mout_cap = 0, zplane_cap = 0;
+    size_t tbuf_cap = 0, mout_cap = 0, zplane_cap = 0, dpm_m_cap = 0;
 
     float* P(const std::string& name) const;
     const dsd::Param& PP(const std::string& name) const;

@@ -9,6 +9,11 @@
 #include "kernels.h"
 #include "../../include/dsdiff.h"
 
+// The reference evaluates these updates as separate fp32 torch ops, so nothing in this file may be contracted into an
+// FMA: plain operators under contract(off) (HIP's __fmul_rn/__fsub_rn are header inlines that stay contractable);
+// fmaf() is written where torch itself fuses.
+#pragma clang fp contract(off)
+
 namespace dsd {
 
 // ---- Philox4x32-10 (Salmon et al. 2011): counter = (idx, step), key = seed
@@ -122,6 +127,141 @@ void sampler_update(const StepCoef& sc, const float* model_out, float* x, const 
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(sampler_update_kernel, dim3(blocks), dim3(256), 0, s, sc, model_out, x, noise, seed, step, B, HW, x0_out);
     check_launch("sampler_update");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// DPM-Solver(++) multistep (Disc_diff/guided_diffusion/sampler.py; twin ldm/models/diffusion/dpm_solver_new/
+// dpm_solver_pytorch.py).  Per network evaluation k:
+//   dpm_model   m_k = data prediction x0 (dpmsolver++, sampler.py:396-405) or noise prediction (:390-394) from the
+//               network output, for model types noise / x_start / v (model_wrapper :247-265)
+//   dpm_quantile  s_b = max(quantile_0.995(|x0_b|), max_val) per sample (dynamic thresholding :379-388, torch.quantile
+//               'linear': sorted[floor(r)] lerp sorted[ceil(r)], r = q*(n-1) in fp32) by an exact 4-pass radix select
+//   dpm_update  m_k <- clamp(m_k,-s,s)/s ; x <- first-order (:509-553) or second-order multistep update (:760-816)
+// Every product/sum is a separately rounded fp32 op in the reference's order (file-wide contract(off)).
+__global__ __launch_bounds__(256) void dpm_model_kernel(DpmCoef c, const float* __restrict__ mo, int Cm,
+                                                        const float* __restrict__ x, float* __restrict__ m, int B,
+                                                        int HW) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / HW;
+        const float out = mo[(b * Cm) * HW + (i - b * HW)];   // a learned-sigma model: first channel only (gaussian_diffusion.py:484-485)
+        const float xt = x[i];
+        float eps;
+        if (c.pred == DSD_PRED_EPS)
+            eps = out;
+        else if (c.pred == DSD_PRED_X0)
+            eps = (xt - c.alpha * out) / c.sigma;
+        else
+            eps = c.alpha * out + c.sigma * xt;
+        m[i] = c.data_pred ? (xt - c.sigma * eps) / c.alpha : eps;
+    }
+}
+
+// One block per sample.  |v| bit patterns of non-negative floats order like unsigned integers, so the element of rank k
+// is found digit by digit (8 bits per pass) with an LDS histogram; the rank k+1 element is either the same value or the
+// smallest value above it.
+__global__ __launch_bounds__(1024) void dpm_quantile_kernel(const float* __restrict__ m, int n, float ratio, float max_val,
+                                                            float* __restrict__ s_out) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh_prefix, sh_k, sh_cnt, sh_min;
+    const float* v = m + (int64_t)blockIdx.x * n;
+    const float rank = ratio * (float)(n - 1);
+    const float fl = floorf(rank);
+    const uint32_t k_below = (uint32_t)fl;
+    const bool need_above = ceilf(rank) != fl;
+    const float w = rank - fl;
+    if (threadIdx.x == 0) { sh_prefix = 0; sh_k = k_below; sh_min = 0xFFFFFFFFu; }
+    uint32_t mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t prefix = sh_prefix;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const uint32_t u = __float_as_uint(v[i]) & 0x7FFFFFFFu;
+            if ((u & mask) == prefix) atomicAdd(&hist[(u >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t k = sh_k, d = 0;
+            while (d < 255 && k >= hist[d]) { k -= hist[d]; ++d; }
+            sh_k = k;
+            sh_cnt = hist[d];
+            sh_prefix = prefix | (d << shift);
+        }
+        mask |= 255u << shift;
+        __syncthreads();
+    }
+    const uint32_t ubelow = sh_prefix;
+    uint32_t uabove = ubelow;
+    if (need_above && sh_k + 1 >= sh_cnt) {      // rank k+1 lies beyond the run of equal values
+        uint32_t loc = 0xFFFFFFFFu;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const uint32_t u = __float_as_uint(v[i]) & 0x7FFFFFFFu;
+            if (u > ubelow && u < loc) loc = u;
+        }
+        atomicMin(&sh_min, loc);
+        __syncthreads();
+        uabove = sh_min;
+    }
+    if (threadIdx.x == 0) {
+        const float a = __uint_as_float(ubelow), b = __uint_as_float(uabove);
+        // at::lerp (ATen/native/Lerp.h, vectorised CPU form): fma(w<0.5 ? w : w-1, b-a, w<0.5 ? a : b)
+        const float diff = b - a;
+        const float q = (fabsf(w) < 0.5f) ? fmaf(w, diff, a) : fmaf(w - 1.0f, diff, b);
+        s_out[blockIdx.x] = fmaxf(q, max_val);
+    }
+}
+
+__global__ __launch_bounds__(256) void dpm_update_kernel(DpmCoef c, float* __restrict__ m0, const float* __restrict__ m1,
+                                                         const float* __restrict__ s_thr, float* __restrict__ x, int B,
+                                                         int HW) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float m = m0[i];
+        if (s_thr) {
+            const float s = s_thr[i / HW];
+            m = fminf(fmaxf(m, -s), s) / s;
+            m0[i] = m;
+        }
+        if (!x) continue;                                     // thresholding only (dsd_op_dpm_threshold)
+        float res;
+        if (c.order == 0) {
+            res = m;                                          // denoise_to_zero_fn :503-507
+        } else {
+            res = c.cx * x[i] - c.cm * m;
+            if (c.order == 2) res = res - c.cd * (c.ir0 * (m - m1[i]));
+        }
+        x[i] = res;
+    }
+}
+
+void dpm_step(const DpmCoef& c, const float* model_out, int Cm, float* x, float* m_cur, const float* m_prev, float* s_buf,
+              float ratio, float max_val, int B, int HW, hipStream_t s) {
+    const int64_t total = (int64_t)B * HW;
+    if (!total) return;
+    const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(dpm_model_kernel, dim3(blocks), dim3(256), 0, s, c, model_out, Cm, x, m_cur, B, HW);
+    check_launch("dpm_model");
+    const bool thr = c.thresh && c.data_pred;
+    if (thr) {
+        hipLaunchKernelGGL(dpm_quantile_kernel, dim3(B), dim3(1024), 0, s, m_cur, HW, ratio, max_val, s_buf);
+        check_launch("dpm_quantile");
+    }
+    hipLaunchKernelGGL(dpm_update_kernel, dim3(blocks), dim3(256), 0, s, c, m_cur, m_prev, thr ? s_buf : nullptr, x, B, HW);
+    check_launch("dpm_update");
+}
+
+void dpm_threshold(const float* x0, float* y, float* s_buf, float ratio, float max_val, int B, int n, hipStream_t s) {
+    if (!B || !n) return;
+    DSD_HIP(hipMemcpyAsync(y, x0, (size_t)B * n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(dpm_quantile_kernel, dim3(B), dim3(1024), 0, s, y, n, ratio, max_val, s_buf);
+    check_launch("dpm_quantile");
+    DpmCoef c{};
+    c.order = 0;
+    hipLaunchKernelGGL(dpm_update_kernel, dim3((unsigned)std::min<int64_t>(((int64_t)B * n + 255) / 256, 4096)), dim3(256), 0, s, c,
+                       y, (const float*)nullptr, s_buf, (float*)nullptr, B, n);
+    check_launch("dpm_update");
+    DSD_HIP(hipStreamSynchronize(s));
 }
 
 __global__ void fill_t_kernel(float* t, int B, float v) {

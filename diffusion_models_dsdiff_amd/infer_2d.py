@@ -85,8 +85,9 @@ def main(argv=None):
                                           noise_schedule=mp.get("noise_schedule", "linear"),
                                           predict_xstart=bool(mp.get("predict_xstart", False)), rescale_timesteps=rescale,
                                           timestep_respacing=respace, parameterization=mp.get("parameterization", "eps"))
-    sample_fn = diffusion.ddim_sample_loop if ss.get("sampler", "ddpm") == "ddim" else diffusion.p_sample_loop
-    extra = {"eta": float(ss.get("ddim_eta", 0))} if ss.get("sampler", "ddpm") == "ddim" else {}
+    which = ss.get("sampler", "ddpm")                       # trainer_use_gaussian_diff.py:597-599
+    sample_fn = {"ddim": diffusion.ddim_sample_loop, "dpm": diffusion.dpm_solver_sample_loop}.get(which, diffusion.p_sample_loop)
+    extra = {"eta": float(ss.get("ddim_eta", 0))} if which == "ddim" else {}
 
     cond_all = np.load(args.input, mmap_mode="r")
     xT_all = np.load(args.x_T, mmap_mode="r") if args.x_T else None

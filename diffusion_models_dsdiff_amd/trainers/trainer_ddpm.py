@@ -58,3 +58,35 @@ class DDPMModel(DDPM):
         """:442-445."""
         return self.p_sample_loop((batch_size, shape[0], shape[1], shape[2]), cond,
                                   return_intermediates=return_intermediates, **kwargs)
+
+    @torch.no_grad()
+    def log_images(self, batch, N=8, n_row=2, sample=True, return_keys=None, sampler="ddim", pred_mode=False,
+                   ddim_eta=0, **kwargs):
+        """:394-440 — the sampler switch of the prediction path (``dpm`` | ``ddim`` | DDPM ancestral).  ``batch`` holds
+        the target under ``first_stage_key`` (shape only) and the condition under ``"image"``."""
+        from ..ldm.models.diffusion.ddim import DDIMSampler
+        from ..ldm.models.diffusion.dpm_solver_new import DPMSolverSampler
+        device = self.betas.device
+        x = batch[getattr(self, "first_stage_key", "t1ce")]
+        c = batch["image"]
+        N = min(x.shape[0], N)
+        x, c = x.to(device)[:N], c.to(device)[:N]
+        log = {"inputs": x}
+        shape = x.shape[1:]
+        for k in ("use_ema_scope",):
+            kwargs.pop(k, None)
+        if sample:
+            if sampler == "dpm":
+                kwargs.pop("ddim_use_original_steps", None)
+                samples, _ = DPMSolverSampler(self).sample(kwargs.pop("ddim_steps"), N, shape, c, **kwargs)
+            elif sampler == "ddim":
+                samples, _ = DDIMSampler(self).sample(kwargs.pop("ddim_steps"), N, shape, c, verbose=False, eta=ddim_eta,
+                                                      **kwargs)
+            else:
+                samples = self.sample(batch_size=N, cond=c, shape=shape)
+            log["samples"] = samples
+        if return_keys:
+            keep = [k for k in log if k in return_keys]
+            if keep:
+                return {k: log[k] for k in keep}
+        return log

@@ -166,6 +166,41 @@ int dsd_sample(dsd_handle* h, const dsd_schedule* sched, const float* cond, int 
 int dsd_op_sampler_update(const dsd_schedule* sched, int k, const float* model_out, float* x, const float* noise,
                           uint64_t philox_seed, int B, int H, int W, float* pred_xstart, void* stream);
 
+/* ---- DPM-Solver(++) multistep sampler -----------------------------------------------------
+ * Replaces DPM_Solver(...).sample(method="multistep", order<=2) of Disc_diff/guided_diffusion/sampler.py:1017-1222
+ * (call site GaussianDiffusion.dpm_solver_sample_loop, gaussian_diffusion.py:467-522) and of its twin
+ * ldm/models/diffusion/dpm_solver_new/dpm_solver_pytorch.py (call site DPMSolverSampler.sample, sampler.py:86-101).
+ * Iteration k evaluates the network once at model time t_input[k] and applies one update:
+ *   m_k  = data prediction (x - sigma_k*eps)/alpha_k [data_pred=1, "dpmsolver++"] or eps [data_pred=0, "dpmsolver"],
+ *          eps from the network output per `pred` (model_wrapper, sampler.py:247-265); with `thresholding` the data
+ *          prediction is dynamically thresholded per sample (sampler.py:379-388)
+ *   order[k] = 1:  x <- cx*x - cm*m_k                                   (dpm_solver_first_update :509-553)
+ *   order[k] = 2:  x <- (cx*x - cm*m_k) - cd*(ir0*(m_k - m_{k-1}))      (multistep_dpm_solver_second_update :760-816)
+ *   order[k] = 0:  x <- thresholded data prediction                     (denoise_to_zero_fn :503-507; forces data_pred)
+ * coef[k*DSD_NCOEF + j]: 0 alpha_k  1 sigma_k  2 cx  3 cm  4 cd  5 ir0 (= 1/r0), all produced on the host with the
+ * reference's fp32 torch expressions (NoiseScheduleVP, sampler.py:76-149). */
+typedef struct dsd_dpm_schedule {
+    int32_t steps;            /* network evaluations (= updates) */
+    int32_t pred;             /* DSD_PRED_* : what the network predicts */
+    int32_t data_pred;        /* 1 = dpmsolver++ (data prediction), 0 = dpmsolver (noise prediction) */
+    int32_t thresholding;     /* dynamic thresholding of the data prediction */
+    float threshold_ratio;    /* 0.995 */
+    float threshold_max;      /* 1.0 */
+    const float* coef;        /* host, steps*DSD_NCOEF */
+    const float* t_input;     /* host, steps: fp32 model time (t - 1/N)*1000, sampler.py:236-245 */
+    const int32_t* order;     /* host, steps */
+} dsd_dpm_schedule;
+/* x: [B,1,H,W] in = x_T, out = sample (in place); cond as in dsd_sample.  A 2-channel (learned-sigma) network
+ * contributes its first channel only (gaussian_diffusion.py:484-485). */
+int dsd_sample_dpm(dsd_handle* h, const dsd_dpm_schedule* sched, const float* cond, int Cc, float* x, int B, int H, int W,
+                   void* stream);
+/* Iteration k's post-network part alone: model_out [B,Cm,H,W], x updated in place, m_cur [B,1,H,W] receives m_k,
+ * m_prev = m_{k-1} (may be NULL when order[k] < 2). */
+int dsd_op_dpm_step(const dsd_dpm_schedule* sched, int k, const float* model_out, int Cm, float* x, float* m_cur,
+                    const float* m_prev, int B, int H, int W, void* stream);
+/* Dynamic thresholding alone: y = clamp(x0,-s,s)/s with s_b = max(quantile_ratio(|x0_b|), max_val); x0,y [B,n], s [B]. */
+int dsd_op_dpm_threshold(const float* x0, int B, int n, float ratio, float max_val, float* y, float* s_out, void* stream);
+
 /* ---- single blocks (own parameter namespace, names relative to the block) ----------------- */
 enum { DSD_BLOCK_RES = 0, DSD_BLOCK_ATTN = 1, DSD_BLOCK_UPSAMPLE = 2, DSD_BLOCK_DOWNSAMPLE = 3,
        DSD_BLOCK_DISENTANGLE = 4, DSD_BLOCK_SE = 5, DSD_BLOCK_CROSSATTN = 6, DSD_BLOCK_FF_GEGLU = 7,

@@ -117,3 +117,89 @@ def test_errors_mirror_reference():
     with pytest.raises(AssertionError):
         gd.GaussianDiffusion(betas=np.array([0.0, 0.1]), model_mean_type=gd.ModelMeanType.EPSILON,
                              model_var_type=gd.ModelVarType.FIXED_LARGE, loss_type=gd.LossType.MSE)
+
+
+# ---------------------------------------------------------------------------------------- DPM-Solver(++) host side
+def _dpm_solver_for(key):
+    import torch
+    from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion import sampler as dsa
+    from util import DPM_CASES, dpm_case_betas
+    src, mtype, kw = DPM_CASES[key]
+    kw = dict(kw)
+    ns = dsa.NoiseScheduleVP("discrete", **dpm_case_betas(src))
+    fn = dsa.model_wrapper(lambda x, t, **k: x, ns, model_type=mtype)
+    sol = dsa.DPM_Solver(fn, ns, algorithm_type=kw.pop("algorithm", "dpmsolver++"),
+                         correcting_x0_fn="dynamic_thresholding" if kw.pop("thresholding", False) else None)
+    return dsa, ns, sol, mtype, kw
+
+
+def test_dpm_noise_schedule_bit_exact():
+    """Product NoiseScheduleVP / get_time_steps against the reference's fp32 values (tests/golden/dpm.npz)."""
+    from util import DPM_CASES
+    g = golden("dpm")
+    for key in DPM_CASES:
+        _, ns, sol, _, kw = _dpm_solver_for(key)
+        assert ns.total_N == int(g[key + "_totalN"])
+        ts = sol.get_time_steps(kw["skip_type"], kw.get("t_start") or ns.T, kw.get("t_end") or 1. / ns.total_N, kw["steps"])
+        np.testing.assert_array_equal(ts.numpy(), g[key + "_ts"], err_msg=key)
+        np.testing.assert_array_equal(ns.marginal_alpha(ts).numpy(), g[key + "_alpha"], err_msg=key)
+        np.testing.assert_array_equal(ns.marginal_std(ts).numpy(), g[key + "_std"], err_msg=key)
+        np.testing.assert_array_equal(ns.marginal_lambda(ts).numpy(), g[key + "_lam"], err_msg=key)
+    import torch
+    from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.sampler import NoiseScheduleVP
+    ns = NoiseScheduleVP("discrete", betas=torch.from_numpy(S.named_beta_schedule("cosine", 1000)).float())
+    assert ns.total_N == int(g["A_cos1000_totalN"]) < 1000             # numerical_clip_alpha
+
+
+def test_dpm_schedule_rows_reproduce_the_oracle_loop():
+    """The coefficient rows handed to dsd_sample_dpm, replayed on the CPU with the device kernels' fp32 operation order
+    (emulated below with torch fp32 ops), must reproduce the oracle's multistep loop on an analytic network: this pins
+    order selection, lower-order-final, denoise-to-zero and every coefficient without a GPU."""
+    import torch
+    from oracle import dpm as odpm
+    from util import DPM_CASES, dpm_case_betas
+    net = lambda x, t: 0.3 * x + torch.sin(t / 1000.)[:, None, None, None] + 0.05 * x.flip(-1)
+    x_T = torch.from_numpy(np.random.default_rng(3).standard_normal((2, 1, 8, 8)).astype(np.float32))
+    for key, (src, mtype, okw) in DPM_CASES.items():
+        _, ns, sol, _, kw = _dpm_solver_for(key)
+        sc = sol.build_schedule(kw.pop("steps"), kw.pop("t_start", None), kw.pop("t_end", None), **kw)
+        f = lambda v: torch.tensor(v, dtype=torch.float32)
+        x, m_prev = x_T.clone(), None
+        for k in range(sc.steps):
+            alpha, sigma, cx, cm, cd, ir0 = (f(v) for v in sc.coef[k, :6])
+            out = net(x, torch.full((2,), float(sc.t_input[k])))
+            eps = out if mtype == "noise" else ((x - alpha * out) / sigma if mtype == "x_start" else alpha * out + sigma * x)
+            data = bool(sc.c.data_pred) or sc.order[k] == 0
+            m = (x - sigma * eps) / alpha if data else eps
+            if sc.c.thresholding and data:
+                m = odpm.dynamic_threshold(m, sc.c.threshold_ratio, sc.c.threshold_max)
+            if sc.order[k] == 0:
+                x = m
+            else:
+                x_new = cx * x - cm * m
+                if sc.order[k] == 2:
+                    x_new = x_new - cd * (ir0 * (m - m_prev))
+                x = x_new
+            m_prev = m
+        want = odpm.dpm_multistep(net, odpm.NoiseSchedule(**dpm_case_betas(src)), x_T.clone(), model_type=mtype, **okw)
+        np.testing.assert_array_equal(x.numpy(), want.numpy(), err_msg=key)
+
+
+def test_dpm_unsupported_options_raise():
+    dsa, ns, sol, _, _ = _dpm_solver_for("B_eps_uniform_6")
+    import torch
+    x = torch.zeros(1, 1, 8, 8)
+    with pytest.raises(NotImplementedError):
+        sol.sample(x, method="singlestep")
+    with pytest.raises(NotImplementedError):
+        sol.sample(x, order=3)
+    with pytest.raises(NotImplementedError):
+        dsa.model_wrapper(lambda x, t: x, ns, guidance_type="classifier")
+    with pytest.raises(NotImplementedError):
+        dsa.DPM_Solver(dsa.model_wrapper(lambda x, t: x, ns), ns, correcting_x0_fn=lambda x0, t: x0)
+    with pytest.raises(TypeError):
+        dsa.DPM_Solver(lambda x, t: x, ns)
+    with pytest.raises(RuntimeError):                                    # CPU tensors never fall back to a CPU loop
+        sol.sample(x, steps=6)
+    with pytest.raises(ValueError):
+        dsa.NoiseScheduleVP("cosine")

@@ -260,3 +260,50 @@ def test_loops_more_branches():
         z = randn((n,) + shape, int(gl2[key + "_noise_seed"]))
         y = d.ddim_sample(model, S_, xT, z, [cond], eta=eta, use_original_steps=orig)
         assert rel_l2(y, gl2[key + "_y"]) < TOL_LOOP, key
+
+
+# ---------------------------------------------------------------------------------------- DPM-Solver(++) multistep
+def test_dpm_schedule_tables():
+    """NoiseScheduleVP('discrete') marginals and get_time_steps against the reference's fp32 values (bit-exact: same
+    torch CPU primitives)."""
+    from oracle import dpm
+    from util import DPM_CASES, dpm_case_betas
+    g = golden("dpm")
+    cases = {k: (v[0], v[2]) for k, v in DPM_CASES.items()}
+    cases["A_cos1000"] = (("cos1000",), dict(steps=15, skip_type="logSNR"))
+    for key, (src, kw) in cases.items():
+        if src[0] == "cos1000":
+            ns = dpm.NoiseSchedule(betas=torch.from_numpy(S.named_beta_schedule("cosine", 1000)).float())
+            assert ns.total_N < 1000                          # numerical_clip_alpha cut the tail
+        else:
+            ns = dpm.NoiseSchedule(**dpm_case_betas(src))
+        assert ns.total_N == int(g[key + "_totalN"]), key
+        t_T = kw.get("t_start") or ns.T
+        t_0 = kw.get("t_end") or 1. / ns.total_N
+        ts = dpm.time_steps(ns, kw["skip_type"], t_T, t_0, kw["steps"])
+        np.testing.assert_array_equal(ts.numpy(), g[key + "_ts"], err_msg=key)
+        np.testing.assert_array_equal(ns.alpha(ts).numpy(), g[key + "_alpha"], err_msg=key)
+        np.testing.assert_array_equal(ns.std(ts).numpy(), g[key + "_std"], err_msg=key)
+        np.testing.assert_array_equal(ns.lam(ts).numpy(), g[key + "_lam"], err_msg=key)
+
+
+def test_dpm_dynamic_threshold():
+    from oracle import dpm
+    g = golden("dpm")
+    for i in range(3):
+        x0 = randn(tuple(int(v) for v in g[f"thr{i}_shape"]), 90 + i) * float(g[f"thr{i}_scale"])
+        np.testing.assert_array_equal(dpm.dynamic_threshold(x0).numpy(), g[f"thr{i}_y"])
+
+
+def test_dpm_multistep_loops():
+    """The whole multistep sampler on the tiny network against the reference's outputs (both solver copies, every
+    branch the drop-in supports)."""
+    from oracle import dpm
+    from util import DPM_CASES, dpm_case_betas
+    g = golden("dpm")
+    _, model, shape, cond, xT = _loop_setup()
+    net = lambda x, t: model(torch.cat([x, cond], 1), t)
+    for key, (src, mtype, kw) in DPM_CASES.items():
+        ns = dpm.NoiseSchedule(**dpm_case_betas(src))
+        y = dpm.dpm_multistep(net, ns, xT.clone(), model_type=mtype, **kw)
+        assert rel_l2(y, g[key + "_y"]) < TOL_LOOP, key

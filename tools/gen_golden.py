@@ -386,7 +386,107 @@ def gen_loops2():
     save("loops2", **out)
 
 
+# ------------------------------------------------------------------ DPM-Solver(++) multistep (tiny model)
+def gen_dpm():
+    """Disc_diff/guided_diffusion/sampler.py through its call site gaussian_diffusion.py:467-522, and the LDM twin
+    ldm/models/diffusion/dpm_solver_new through DPMSolverSampler-style arguments (sampler.py:86-101)."""
+    import Disc_diff.guided_diffusion.gaussian_diffusion as gd
+    import Disc_diff.guided_diffusion.sampler as sa
+    import ldm.models.diffusion.dpm_solver_new.dpm_solver_pytorch as sb
+    from Disc_diff.guided_diffusion.respace import space_timesteps, SpacedDiffusion
+    from ldm.modules.diffusionmodules.util import make_beta_schedule
+    out = {}
+    m, ps = tiny_model(TINY, 200)
+    shape = (2, 1, 32, 32)
+    cond = cond_image(shape, 80)
+    x_T = randn(shape, 81)
+
+    class W(torch.nn.Module):            # dpm_solver_sample_loop asks the model for next(parameters()).device
+        def __init__(self):
+            super().__init__()
+            self.m = m
+
+        def forward(self, x, t, c_concat=None):
+            return self.m(torch.cat([x] + c_concat, 1), t)[0]
+    w = W()
+
+    def tables(key, mod, ns, skip, steps, t_T=None, t_0=None):
+        sol = mod.DPM_Solver(lambda x, t: x, ns)
+        ts = sol.get_time_steps(skip, ns.T if t_T is None else t_T, 1. / ns.total_N if t_0 is None else t_0, steps, "cpu")
+        out[key + "_ts"] = ts.numpy()
+        out[key + "_alpha"] = torch.stack([ns.marginal_alpha(t) for t in ts]).reshape(-1).numpy()
+        out[key + "_std"] = torch.stack([ns.marginal_std(t) for t in ts]).reshape(-1).numpy()
+        out[key + "_lam"] = torch.stack([ns.marginal_lambda(t) for t in ts]).reshape(-1).numpy()
+        out[key + "_totalN"] = np.asarray(ns.total_N)
+
+    # (A) the reference's own entry point: respaced betas, steps = num_timesteps, logSNR, order 2, thresholding
+    for key, resp, sched in (("A_dpm_20", "20", "linear"), ("A_dpm_cos_12", "12", "cosine")):
+        b = gd.get_named_beta_schedule(sched, 1000)
+        diff = SpacedDiffusion(use_timesteps=space_timesteps(1000, resp), betas=b,
+                               model_mean_type=gd.ModelMeanType.EPSILON, model_var_type=gd.ModelVarType.FIXED_LARGE,
+                               loss_type=gd.LossType.MSE, rescale_timesteps=True, parameterization="eps")
+        orig = torch.randn
+        torch.randn = lambda *a, **k: x_T.clone()
+        try:
+            y = diff.dpm_solver_sample_loop(w, shape, model_kwargs=dict(c_concat=[cond]))
+        finally:
+            torch.randn = orig
+        out[key + "_y"] = y.numpy()
+        ns = sa.NoiseScheduleVP("discrete", betas=torch.from_numpy(diff.betas).float())
+        tables(key, sa, ns, "logSNR", diff.num_timesteps)
+
+    # full (unspaced) cosine schedule: exercises numerical_clip_alpha's cut
+    ns = sa.NoiseScheduleVP("discrete", betas=torch.from_numpy(gd.get_named_beta_schedule("cosine", 1000)).float())
+    tables("A_cos1000", sa, ns, "logSNR", 15)
+
+    # (B) the LDM twin and the remaining branches of sample(method='multistep')
+    betas_b = torch.tensor(make_beta_schedule("linear", 1000, 1e-4, 2e-2), dtype=torch.float32)
+    ac_b = torch.tensor(np.cumprod(1. - make_beta_schedule("linear", 1000, 1e-4, 2e-2), axis=0), dtype=torch.float32)
+    cases = (
+        # key, module, ns kwargs, model_type, DPM_Solver kwargs, sample kwargs
+        ("B_v_uniform_10", sb, dict(betas=betas_b), "v", dict(algorithm_type="dpmsolver++"),
+         dict(steps=10, skip_type="time_uniform", method="multistep", order=2)),
+        ("B_v_uniform_6_lof", sb, dict(betas=betas_b), "v", dict(algorithm_type="dpmsolver++"),
+         dict(steps=6, skip_type="time_uniform", method="multistep", order=2)),
+        ("B_eps_uniform_6", sb, dict(betas=betas_b), "noise", dict(algorithm_type="dpmsolver++"),
+         dict(steps=6, skip_type="time_uniform", method="multistep", order=2)),
+        ("B_eps_acp_quad_7_thr", sb, dict(alphas_cumprod=ac_b), "noise",
+         dict(algorithm_type="dpmsolver++", correcting_x0_fn="dynamic_thresholding"),
+         dict(steps=7, skip_type="time_quadratic", method="multistep", order=2, lower_order_final=False)),
+        ("B_x0_order1_5", sb, dict(betas=betas_b), "x_start", dict(algorithm_type="dpmsolver++"),
+         dict(steps=5, skip_type="time_uniform", method="multistep", order=1)),
+        ("B_eps_dz_6", sb, dict(betas=betas_b), "noise",
+         dict(algorithm_type="dpmsolver++", correcting_x0_fn="dynamic_thresholding"),
+         dict(steps=6, skip_type="logSNR", method="multistep", order=2, denoise_to_zero=True)),
+        ("B_eps_plain_8", sb, dict(betas=betas_b), "noise", dict(algorithm_type="dpmsolver"),
+         dict(steps=8, skip_type="time_uniform", method="multistep", order=2)),
+        ("B_v_taylor_8", sb, dict(betas=betas_b), "v", dict(algorithm_type="dpmsolver++"),
+         dict(steps=8, skip_type="time_uniform", method="multistep", order=2, solver_type="taylor")),
+        ("B_eps_plain_taylor_range_6", sb, dict(betas=betas_b), "noise", dict(algorithm_type="dpmsolver"),
+         dict(steps=6, skip_type="logSNR", method="multistep", order=2, solver_type="taylor", t_start=0.8, t_end=0.02,
+              lower_order_final=False)),
+    )
+    for key, mod, nskw, mtype, solkw, smpkw in cases:
+        ns = mod.NoiseScheduleVP("discrete", **nskw)
+        fn = mod.model_wrapper(lambda x, t, c: w(x, t, c_concat=c["c_concat"]), ns, model_type=mtype,
+                               guidance_type="classifier-free", condition=dict(c_concat=[cond]),
+                               unconditional_condition=None, guidance_scale=1.)
+        y = mod.DPM_Solver(fn, ns, **solkw).sample(x_T.clone(), **smpkw)
+        out[key + "_y"] = y.numpy()
+        tables(key, mod, ns, smpkw["skip_type"], smpkw["steps"], smpkw.get("t_start"), smpkw.get("t_end"))
+    out["cond_seed"], out["xT_seed"] = np.asarray(80), np.asarray(81)
+
+    # dynamic thresholding alone on seeded inputs (torch.quantile semantics)
+    sol = sa.DPM_Solver(lambda x, t: x, ns, correcting_x0_fn="dynamic_thresholding")
+    for i, (shp, scale) in enumerate((((3, 1, 32, 32), 2.5), ((2, 1, 64, 64), 0.3), ((2, 1, 17, 23), 40.0))):
+        x0 = randn(shp, 90 + i) * scale
+        out[f"thr{i}_shape"], out[f"thr{i}_scale"] = np.asarray(shp), np.asarray(scale)
+        out[f"thr{i}_y"] = sol.dynamic_thresholding_fn(x0, None).numpy()
+        out[f"thr{i}_s"] = torch.quantile(torch.abs(x0).reshape(shp[0], -1), 0.995, dim=1).numpy()
+    save("dpm", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "ops", "xattn", "model", "loops", "loops2"]
+    which = sys.argv[1:] or ["schedules", "ops", "xattn", "model", "loops", "loops2", "dpm"]
     for w in which:
         globals()["gen_" + w]()
