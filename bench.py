@@ -256,6 +256,24 @@ def main():
                     "computed at batch 1 (SURVEY.md 7: must be reported separately)"}
         _lib.check(_lib.lib().dsd_plan(model._h, B, 2, H, W))
 
+    # separate line (never part of `value`): the 20-evaluation DPM-Solver++ sampler of the reference
+    # (gaussian_diffusion.py:467-522), whole samples end to end through dsd_sample_dpm
+    samplers = None
+    if world == 1 and not args.no_modes:
+        d20 = create_gaussian_diffusion(steps=1000, timestep_respacing="20", rescale_timesteps=True,
+                                        parameterization=mp.get("parameterization", "eps"))
+        x_T = torch.randn(B, 1, H, W, device=dev, generator=g)
+        barrier()
+        t1 = time.time()
+        y = d20.dpm_solver_sample_loop(model, (B, 1, H, W), model_kwargs=dict(c_concat=[cond]), noise=x_T)
+        barrier()
+        dt = time.time() - t1
+        samplers = {"dpm_solver++_multistep2_20": {
+            "network_evaluations": 20, "seconds_per_batch": round(dt, 3), "slices_per_s": round(B / dt, 4),
+            "ms_per_evaluation": round(dt / 20 * 1e3, 2), "finite": bool(torch.isfinite(y).all()),
+            "note": "logSNR spacing, order 2, dynamic thresholding (radix-select quantile) — a different sampler, not the "
+                    "1000-step metric"}}
+
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
@@ -285,6 +303,7 @@ def main():
             "cpu_baseline": cpu,
             "kernels": kernels,
             "modes": modes,
+            "samplers": samplers,
             "extra": {"gpu": gpu_name, "compute_units": n_cu, "finite_output": finite,
                       "workspace_GiB": round(info["workspace_bytes"] / 2 ** 30, 2), "launches_per_step": info["launches"],
                       "executed_flops_per_step": info["flops"],
