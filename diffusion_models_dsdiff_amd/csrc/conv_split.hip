@@ -369,7 +369,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
     constexpr int BROWS = NT * 32;
     constexpr int B_PLANE = BROWS * RSB;
     constexpr int NBL = (BROWS * 4 * NP + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[NP * B_PLANE];
+    // Two LDS stages for the weight tile: tile kt is written into stage kt&1 while slower waves may still be reading tile
+    // kt-1 from the other stage, so ONE barrier per k-tile is enough (stage kt&1 was last read for tile kt-2, and every
+    // wave has passed the barrier of tile kt-1 since).  The last 16 B x 256 are per-thread dummy slots: the threads of
+    // the final, partly filled staging round write there instead of branching on the exec mask.
+    constexpr int STAGE = NP * B_PLANE;
+    constexpr int NSTAGE = (2 * STAGE + 4096) * 2 <= 160 * 1024 ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[NSTAGE * STAGE + 256 * 16];
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
@@ -407,12 +413,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
     }
     unsigned a_voff[4];   // the four 16-byte pieces of this lane's two 8-float slots; OOB must not wrap when offset
     auto tap_offsets = [&](int kh, int kw) {
-        int ih = a_h + kh, iw = a_w + kw;
-        const bool ok = a_ok && (unsigned)ih < (unsigned)p.IHg && (unsigned)iw < (unsigned)p.IWg;
-        if (p.ups) {
-            ih >>= 1;
-            iw >>= 1;
-        }
+        int ih = a_h + kh, iw = a_w + kw;   // branch-free: this runs inside the MFMA stream
+        const bool ok = a_ok & ((unsigned)ih < (unsigned)p.IHg) & ((unsigned)iw < (unsigned)p.IWg);
+        ih >>= p.ups;
+        iw >>= p.ups;
         const unsigned base = (a_nb + (unsigned)(ih * p.W + iw) * (unsigned)p.Cin) * 4u;
         a_voff[0] = ok ? base : OOB;
         a_voff[1] = ok ? base + 16u : OOB;
@@ -436,14 +440,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
         b_voff[i] = ok ? (unsigned)piece * p.w_plane_bytes + ((unsigned)n * (unsigned)p.Ktot) * 2u + (unsigned)(ch * 16) : OOB;
         b_lds[i] = piece < NP ? piece * B_PLANE + row * RSB + ch * 16 : -1;
     }
+    const int b_dummy = NSTAGE * STAGE + tid * 16;
     f32x4 ra[4];   // [k-step][lo/hi 4 floats]
     u32x4 rb[NBL];
-    auto load_tile = [&](int soff_a, int soff_b) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[i], soff_a, 0));
-#pragma unroll
-        for (int i = 0; i < NBL; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff_b, 0);
-    };
 
     f32x16 acc[NT];
 #pragma unroll
@@ -462,52 +461,120 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
         c = Elt<F16>::mfma(a[0], b[0], c);
     };
 
+    // ---- software pipeline over the k-tiles (one barrier per tile, nothing but that barrier and the first fragment
+    // read outside the MFMA stream).  While tile kt is multiplied:
+    //   first k-step  (units 0..NT-1):   the weight tile kt+1 (already in registers) is written into the OTHER LDS stage,
+    //                                    then the loads of weight tile kt+2 are issued
+    //   second k-step (units NT..2NT-1): the activations of tile kt+1 (already in registers) are split into pieces — the
+    //                                    first k-step's straight into af[0], whose old value is dead by then — and the loads
+    //                                    of the activations of tile kt+2 are issued
+    // A unit = the 2*NP MFMAs of one k-step on one accumulator; each unit first issues the LDS reads of the NEXT unit's
+    // weight fragments (sched_barriers pin that order: left alone, the compiler waits on LDS in front of most MFMAs).
+    static_assert(NSTAGE == 2, "the pipelined A-direct kernel needs both weight stages");
+    constexpr int U = 2 * NT;
     const int KT = p.ks * p.ks * p.cchunks;
     int kh = 0, kw = 0, cc = 0, tap = 0;
-    tap_offsets(0, 0);
-    load_tile(0, 0);
+    // counters of the next tile to LOAD, branch-free (scalar selects): the loop body below is one basic block so that the
+    // compiler can interleave the staging work with the MFMAs.  Past the last tile the counters run on harmlessly: the
+    // loads are range-checked by the buffer resources (or hit valid activations) and their data is never multiplied.
+    auto advance = [&]() {
+        const bool wrap = cc + 1 == p.cchunks;
+        cc = wrap ? 0 : cc + 1;
+        tap += wrap ? 1 : 0;
+        const bool wrapw = wrap && (kw + 1 == p.ks);
+        kw = wrap ? (wrapw ? 0 : kw + 1) : kw;
+        kh += wrapw ? 1 : 0;
+    };
+    auto load_a = [&]() {
+        const int soff_a = __builtin_amdgcn_readfirstlane(cc * (SBK * 4));   // uniform by construction; keeps it scalar
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[i], soff_a, 0));
+    };
+    auto load_b = [&]() {
+        // clamped: the two look-ahead loads past the last tile re-read the last tile instead of running off the planes
+        const int soff_b = __builtin_amdgcn_readfirstlane(min((tap * p.Cin + cc * SBK) * 2, (p.Ktot - SBK) * 2));
+#pragma unroll
+        for (int i = 0; i < NBL; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff_b, 0);
+    };
+    auto store_b = [&](int i, int so) {
+        if (256 * (i + 1) <= BROWS * 4 * NP)   // compile-time: this staging round is full
+            *reinterpret_cast<u32x4*>(Bs + so + b_lds[i]) = rb[i];
+        else
+            *reinterpret_cast<u32x4*>(Bs + (b_lds[i] >= 0 ? so + b_lds[i] : b_dummy)) = rb[i];
+    };
+    auto join = [&](const u32x2 (&lo)[NP], const u32x2 (&hi)[NP], bf16x8 (&out)[NP]) {
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            u32x4 v;
+            v.x = lo[q].x; v.y = lo[q].y; v.z = hi[q].x; v.w = hi[q].y;
+            out[q] = __builtin_bit_cast(bf16x8, v);
+        }
+    };
+
     bf16x8 af[2][NP];   // A fragments of the current tile (both k-steps), in registers
+    bf16x8 afn1[NP];    // second k-step of the next tile (af[1] is live until the last unit)
+    // prologue: tile 0 -> af / LDS stage 0, tile 1 -> ra / rb in flight
+    tap_offsets(0, 0);
+    load_a();
+    load_b();
+    split8<NP, F16>(ra[0], ra[1], af[0], p.ovf);
+    split8<NP, F16>(ra[2], ra[3], af[1], p.ovf);
+#pragma unroll
+    for (int i = 0; i < NBL; ++i) store_b(i, 0);
+    advance();
+    tap_offsets(kh, kw);
+    load_a();
+    load_b();
+
     for (int kt = 0; kt < KT; ++kt) {
-        // the held registers are tile kt: split A into pieces, publish B through LDS
-        split8<NP, F16>(ra[0], ra[1], af[0], p.ovf);
-        split8<NP, F16>(ra[2], ra[3], af[1], p.ovf);
-        __syncthreads();   // every wave finished reading the previous B tile
-#pragma unroll
-        for (int i = 0; i < NBL; ++i)
-            if (b_lds[i] >= 0) *reinterpret_cast<u32x4*>(Bs + b_lds[i]) = rb[i];
-        __syncthreads();
-        if (kt + 1 < KT) {
-            if (++cc == p.cchunks) {
-                cc = 0;
-                ++tap;
-                if (++kw == p.ks) {
-                    kw = 0;
-                    ++kh;
-                }
-                tap_offsets(kh, kw);
-            }
-            load_tile(cc * (SBK * 4), (tap * p.Cin + cc * SBK) * 2);
-        }
+        const int so = (kt & 1) * STAGE;
+        __syncthreads();   // weight tile kt is visible; every wave is done with the other stage (tile kt-1)
         bf16x8 b_cur[NP], b_nxt[NP];
+        const unsigned char* bf = b_frag + so;
+        u32x2 pl[NP], ph[NP];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) b_nxt[q] = b_cur[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE);
+        for (int q = 0; q < NP; ++q) b_nxt[q] = b_cur[q] = *reinterpret_cast<const bf16x8*>(bf + q * B_PLANE);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int u = 0; u < U; ++u) {
+            const int s = u / NT, j = u % NT;
+            if (u + 1 < U) {
+                const int s1 = (u + 1) / NT, j1 = (u + 1) % NT;
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                if (j + 1 < NT) {
-#pragma unroll
-                    for (int q = 0; q < NP; ++q)
-                        b_nxt[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE + (j + 1) * 32 * RSB + s * 32);
-                } else if (s == 0) {
-#pragma unroll
-                    for (int q = 0; q < NP; ++q) b_nxt[q] = *reinterpret_cast<const bf16x8*>(b_frag + q * B_PLANE + 32);
-                }
-                mfma_group(af[s], b_cur, acc[j]);
-#pragma unroll
-                for (int q = 0; q < NP; ++q) b_cur[q] = b_nxt[q];
+                for (int q = 0; q < NP; ++q)
+                    b_nxt[q] = *reinterpret_cast<const bf16x8*>(bf + q * B_PLANE + j1 * 32 * RSB + s1 * 32);
             }
+            __builtin_amdgcn_sched_barrier(0);
+            if (s == 0) {   // weight tile kt+1 -> the other stage, spread over the first k-step's units
+#pragma unroll
+                for (int i = 0; i < NBL; ++i)
+                    if (i * NT / NBL == j) store_b(i, STAGE - so);
+                if (j == NT - 1) {
+                    advance();
+                    load_b();
+                }
+            } else {        // activations of tile kt+1 -> pieces
+                if (j == 0) split4<NP, F16>(ra[0], pl, p.ovf);
+                if (j == (NT > 1 ? 1 : 0)) {
+                    split4<NP, F16>(ra[1], ph, p.ovf);
+                    join(pl, ph, af[0]);
+                }
+                if (j == (NT > 2 ? 2 : NT - 1)) split4<NP, F16>(ra[2], pl, p.ovf);
+                if (j == (NT > 3 ? 3 : NT - 1)) {
+                    split4<NP, F16>(ra[3], ph, p.ovf);
+                    join(pl, ph, afn1);
+                    tap_offsets(kh, kw);
+                    load_a();
+                }
+            }
+            mfma_group(af[s], b_cur, acc[j]);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) b_cur[q] = b_nxt[q];
+            __builtin_amdgcn_sched_barrier(0);
         }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) af[1][q] = afn1[q];
     }
     split_epilogue<NT>(p, acc, m0, n0, wave, lrow, half);
 }
