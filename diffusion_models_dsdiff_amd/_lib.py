@@ -10,7 +10,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsdiff.so")
+LIB_PATH = os.environ.get("DSD_LIBRARY") or os.path.join(_HERE, "libdsdiff.so")   # DSD_LIBRARY: A/B builds (tools/)
 CSRC = os.path.join(_HERE, "csrc")
 
 DSD_MAX_LEVELS = 8

@@ -451,7 +451,10 @@ int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride,
     a.x = x.as<float>(); a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.w = w.as<float>(); a.bias = b.as<float>();
     a.Cout = Cout; a.ks = ks; a.stride = stride; a.y = y.as<float>(); a.variant = variant >= 10 ? -1 : variant;
     Tmp planes(nw * 2 * 3);
-    if (variant >= 30) {  // 30 = bf16x3 A-direct, 31 = bf16x6 A-direct (forced)
+    if (variant >= 40) {  // 40 = bf16x3, 41 = bf16x6, 42 = f16x3 on the 256-row A-direct tile (forced)
+        a.variant = 32;
+        variant -= 30;
+    } else if (variant >= 30) {  // 30 = bf16x3 A-direct, 31 = bf16x6 A-direct (forced)
         a.variant = 30;
         variant -= 20;
     } else if (variant >= 20) {  // 20 = bf16x3 staged, 21 = bf16x6 staged (forced)
@@ -500,6 +503,7 @@ int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float
         a.ovf = f16 ? ovf.as<int>() : nullptr;
         if (precision & 16) a.variant = 30;   // force the A-direct structure
         if (precision & 32) a.variant = 31;   // force the staged structure
+        if (precision & 64) a.variant = 32;   // force the 256-row A-direct tile
     }
     conv2d(a, s);
     int flag = 0;

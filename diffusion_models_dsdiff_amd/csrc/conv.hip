@@ -531,7 +531,7 @@ static int pick_nt(int Cout, int tiles_m, int precision) {
 // and measurably faster on the fp32 kernel (8x8 layers at batch 16: 0.195 ms vs 0.275 ms), so those stay fp32.
 static int effective_precision(const ConvArgs& a, int tiles_m) {
     if (a.precision == PREC_F32 || !conv2d_split_eligible(a)) return PREC_F32;
-    if (a.variant == 30 || a.variant == 31) return a.precision;   // structure forced by a test
+    if (a.variant >= 30 && a.variant <= 32) return a.precision;   // structure forced by a test
     const int nt = pick_nt(a.Cout, tiles_m, a.precision);
     if ((int64_t)tiles_m * cdiv(cdiv(a.Cout, 32), nt) <= 256) return PREC_F32;
     return a.precision;

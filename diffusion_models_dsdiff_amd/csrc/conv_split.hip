@@ -105,9 +105,9 @@ __device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NP], int* ovf = nul
 // ---- accumulators -> memory: bias + per-(sample,channel) embedding + residual (same fusion as the fp32 kernel)
 template <int NT>
 __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&acc)[NT], int m0, int n0, int wave, int lrow,
-                                               int half) {
+                                               int half, int tile_rows = SBM) {
     constexpr int BROWS = NT * 32;
-    const bool interior = (m0 + SBM <= p.M) && (n0 + BROWS <= p.Cout) && !p.out_nchw;
+    const bool interior = (m0 + tile_rows <= p.M) && (n0 + BROWS <= p.Cout) && !p.out_nchw;
     if (interior) {
         float bj[NT];
 #pragma unroll
@@ -363,19 +363,22 @@ __device__ __forceinline__ void split8(f32x4 lo, f32x4 hi, typename Elt<F16>::v8
     }
 }
 
-template <int NT, int NP, bool F16>
-__global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
+// RB = 32-row blocks per wave.  RB = 1: block tile 128 x 32*NT, two workgroups per CU.  RB = 2: block tile 256 x 32*NT,
+// ONE workgroup per CU (accumulators alone are 2*NT*16 registers): every weight fragment read from LDS feeds two MFMA
+// groups, which halves the LDS traffic per MFMA, and a k-tile carries twice the MFMAs per barrier.
+template <int NT, int NP, bool F16, int RB>
+__global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(SplitP p) {
     typedef typename Elt<F16>::v8 bf16x8;
     constexpr int BROWS = NT * 32;
     constexpr int B_PLANE = BROWS * RSB;
     constexpr int NBL = (BROWS * 4 * NP + 255) / 256;
-    // Two LDS stages for the weight tile: tile kt is written into stage kt&1 while slower waves may still be reading tile
-    // kt-1 from the other stage, so ONE barrier per k-tile is enough (stage kt&1 was last read for tile kt-2, and every
-    // wave has passed the barrier of tile kt-1 since).  The last 16 B x 256 are per-thread dummy slots: the threads of
-    // the final, partly filled staging round write there instead of branching on the exec mask.
+    // Two LDS stages for the weight tile: tile kt+1 is written into stage (kt+1)&1 while tile kt is read from the other
+    // one, so ONE barrier per k-tile is enough (stage (kt+1)&1 was last read for tile kt-1, and every wave has passed the
+    // barrier of tile kt since).  The last 16 B x 256 are per-thread dummy slots: the threads of the final, partly filled
+    // staging round write there instead of branching on the exec mask.
     constexpr int STAGE = NP * B_PLANE;
-    constexpr int NSTAGE = (2 * STAGE + 4096) * 2 <= 160 * 1024 ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[NSTAGE * STAGE + 256 * 16];
+    static_assert((2 * STAGE + 4096) * (RB == 1 ? 2 : 1) <= 160 * 1024, "both weight stages of the resident workgroups must fit the LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * STAGE + 256 * 16];
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
@@ -392,36 +395,40 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
     }
     const int tile_n = L % p.tiles_n;
     const int tile_m = L / p.tiles_n;
-    const int m0 = tile_m * SBM;
+    const int m0 = tile_m * (SBM * RB);
     const int n0 = tile_n * BROWS;
 
-    // ---- A: this lane's output pixel (row of the implicit GEMM) and its 8-float slot inside a 16-k step
-    int a_h, a_w;
-    unsigned a_nb;
-    bool a_ok;
-    {
-        int m = m0 + wave * 32 + lrow;
-        a_ok = m < p.M;
-        m = a_ok ? m : 0;
+    // ---- A: this lane's RB output pixels (rows of the implicit GEMM) and its 8-float slot inside a 16-k step
+    int a_h[RB], a_w[RB];
+    unsigned a_nb[RB];
+    bool a_ok[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        int m = m0 + (wave * RB + r) * 32 + lrow;
+        a_ok[r] = m < p.M;
+        m = a_ok[r] ? m : 0;
         const int n = m / p.ohw;
-        const int r = m - n * p.ohw;
-        const int oh = r / p.OW;
-        const int ow = r - oh * p.OW;
-        a_h = oh * p.stride - p.pad;
-        a_w = ow * p.stride - p.pad;
-        a_nb = (unsigned)n * (unsigned)p.x_bs + (unsigned)(half * 8);
+        const int rem = m - n * p.ohw;
+        const int oh = rem / p.OW;
+        const int ow = rem - oh * p.OW;
+        a_h[r] = oh * p.stride - p.pad;
+        a_w[r] = ow * p.stride - p.pad;
+        a_nb[r] = (unsigned)n * (unsigned)p.x_bs + (unsigned)(half * 8);
     }
-    unsigned a_voff[4];   // the four 16-byte pieces of this lane's two 8-float slots; OOB must not wrap when offset
-    auto tap_offsets = [&](int kh, int kw) {
-        int ih = a_h + kh, iw = a_w + kw;   // branch-free: this runs inside the MFMA stream
-        const bool ok = a_ok & ((unsigned)ih < (unsigned)p.IHg) & ((unsigned)iw < (unsigned)p.IWg);
-        ih >>= p.ups;
-        iw >>= p.ups;
-        const unsigned base = (a_nb + (unsigned)(ih * p.W + iw) * (unsigned)p.Cin) * 4u;
-        a_voff[0] = ok ? base : OOB;
-        a_voff[1] = ok ? base + 16u : OOB;
-        a_voff[2] = ok ? base + 64u : OOB;
-        a_voff[3] = ok ? base + 80u : OOB;
+    unsigned a_voff[RB][4];   // the four 16-byte pieces of a row's two 8-float slots; OOB must not wrap when offset
+    auto tap_offsets = [&](int kh, int kw) {   // branch-free: this runs inside the MFMA stream
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            int ih = a_h[r] + kh, iw = a_w[r] + kw;
+            const bool ok = a_ok[r] & ((unsigned)ih < (unsigned)p.IHg) & ((unsigned)iw < (unsigned)p.IWg);
+            ih >>= p.ups;
+            iw >>= p.ups;
+            const unsigned base = (a_nb[r] + (unsigned)(ih * p.W + iw) * (unsigned)p.Cin) * 4u;
+            a_voff[r][0] = ok ? base : OOB;
+            a_voff[r][1] = ok ? base + 16u : OOB;
+            a_voff[r][2] = ok ? base + 64u : OOB;
+            a_voff[r][3] = ok ? base + 80u : OOB;
+        }
     };
     // ---- B staging (as in the staged kernel)
     unsigned b_voff[NBL];
@@ -440,15 +447,17 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
         b_voff[i] = ok ? (unsigned)piece * p.w_plane_bytes + ((unsigned)n * (unsigned)p.Ktot) * 2u + (unsigned)(ch * 16) : OOB;
         b_lds[i] = piece < NP ? piece * B_PLANE + row * RSB + ch * 16 : -1;
     }
-    const int b_dummy = NSTAGE * STAGE + tid * 16;
-    f32x4 ra[4];   // [k-step][lo/hi 4 floats]
+    const int b_dummy = 2 * STAGE + tid * 16;
+    f32x4 ra[RB][4];   // [row block][k-step lo/hi 4 floats]
     u32x4 rb[NBL];
 
-    f32x16 acc[NT];
+    f32x16 acc[RB][NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j)
+    for (int r = 0; r < RB; ++r)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[r][j][e] = 0.f;
     const unsigned char* b_frag = Bs + lrow * RSB + half * 16;
     auto mfma_group = [&](const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], f32x16& c) {
         if (NP == 3) {
@@ -467,11 +476,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
     //                                    then the loads of weight tile kt+2 are issued
     //   second k-step (units NT..2NT-1): the activations of tile kt+1 (already in registers) are split into pieces — the
     //                                    first k-step's straight into af[0], whose old value is dead by then — and the loads
-    //                                    of the activations of tile kt+2 are issued
-    // A unit = the 2*NP MFMAs of one k-step on one accumulator; each unit first issues the LDS reads of the NEXT unit's
-    // weight fragments (sched_barriers pin that order: left alone, the compiler waits on LDS in front of most MFMAs).
-    static_assert(NSTAGE == 2, "the pipelined A-direct kernel needs both weight stages");
+    //                                    of the activations of tile kt+2 are issued row block by row block
+    // A unit = the RB*2*NP MFMAs of one k-step on one accumulator column; each unit first issues the LDS reads of the NEXT
+    // unit's weight fragments (sched_barriers pin that order: left alone, the compiler waits on LDS in front of most MFMAs).
     constexpr int U = 2 * NT;
+    constexpr int NTASK = 4 * RB;   // split4 calls per tile
     const int KT = p.ks * p.ks * p.cchunks;
     int kh = 0, kw = 0, cc = 0, tap = 0;
     // counters of the next tile to LOAD, branch-free (scalar selects): the loop body below is one basic block so that the
@@ -485,11 +494,11 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
         kw = wrap ? (wrapw ? 0 : kw + 1) : kw;
         kh += wrapw ? 1 : 0;
     };
-    auto load_a = [&]() {
+    auto load_a = [&](int r) {
         const int soff_a = __builtin_amdgcn_readfirstlane(cc * (SBK * 4));   // uniform by construction; keeps it scalar
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[i], soff_a, 0));
+            ra[r][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[r][i], soff_a, 0));
     };
     auto load_b = [&]() {
         // clamped: the two look-ahead loads past the last tile re-read the last tile instead of running off the planes
@@ -512,19 +521,24 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
         }
     };
 
-    bf16x8 af[2][NP];   // A fragments of the current tile (both k-steps), in registers
-    bf16x8 afn1[NP];    // second k-step of the next tile (af[1] is live until the last unit)
+    bf16x8 af[2][RB][NP];   // A fragments of the current tile (both k-steps), in registers
+    bf16x8 afn1[RB][NP];    // second k-step of the next tile (af[1] is live until the last unit)
     // prologue: tile 0 -> af / LDS stage 0, tile 1 -> ra / rb in flight
     tap_offsets(0, 0);
-    load_a();
+#pragma unroll
+    for (int r = 0; r < RB; ++r) load_a(r);
     load_b();
-    split8<NP, F16>(ra[0], ra[1], af[0], p.ovf);
-    split8<NP, F16>(ra[2], ra[3], af[1], p.ovf);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+        split8<NP, F16>(ra[r][0], ra[r][1], af[0][r], p.ovf);
+        split8<NP, F16>(ra[r][2], ra[r][3], af[1][r], p.ovf);
+    }
 #pragma unroll
     for (int i = 0; i < NBL; ++i) store_b(i, 0);
     advance();
     tap_offsets(kh, kw);
-    load_a();
+#pragma unroll
+    for (int r = 0; r < RB; ++r) load_a(r);
     load_b();
 
     for (int kt = 0; kt < KT; ++kt) {
@@ -554,29 +568,38 @@ __global__ __launch_bounds__(256, 2) void conv_split_ad_kernel(SplitP p) {
                     advance();
                     load_b();
                 }
-            } else {        // activations of tile kt+1 -> pieces
-                if (j == 0) split4<NP, F16>(ra[0], pl, p.ovf);
-                if (j == (NT > 1 ? 1 : 0)) {
-                    split4<NP, F16>(ra[1], ph, p.ovf);
-                    join(pl, ph, af[0]);
-                }
-                if (j == (NT > 2 ? 2 : NT - 1)) split4<NP, F16>(ra[2], pl, p.ovf);
-                if (j == (NT > 3 ? 3 : NT - 1)) {
-                    split4<NP, F16>(ra[3], ph, p.ovf);
-                    join(pl, ph, afn1);
-                    tap_offsets(kh, kw);
-                    load_a();
+            } else {        // activations of tile kt+1 -> pieces, task t = (row block, 4-float slot) in unit t*NT/NTASK
+                if (j == 0) tap_offsets(kh, kw);   // of the tile advance() moved to; its loads follow once ra is free
+#pragma unroll
+                for (int t = 0; t < NTASK; ++t) {
+                    if (t * NT / NTASK != j) continue;
+                    const int r = t / 4, i = t % 4;
+                    if (i == 0) split4<NP, F16>(ra[r][0], pl, p.ovf);
+                    if (i == 1) {
+                        split4<NP, F16>(ra[r][1], ph, p.ovf);
+                        join(pl, ph, af[0][r]);
+                    }
+                    if (i == 2) split4<NP, F16>(ra[r][2], pl, p.ovf);
+                    if (i == 3) {
+                        split4<NP, F16>(ra[r][3], ph, p.ovf);
+                        join(pl, ph, afn1[r]);
+                        load_a(r);
+                    }
                 }
             }
-            mfma_group(af[s], b_cur, acc[j]);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) mfma_group(af[s][r], b_cur, acc[r][j]);
 #pragma unroll
             for (int q = 0; q < NP; ++q) b_cur[q] = b_nxt[q];
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
-        for (int q = 0; q < NP; ++q) af[1][q] = afn1[q];
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int q = 0; q < NP; ++q) af[1][r][q] = afn1[r][q];
     }
-    split_epilogue<NT>(p, acc, m0, n0, wave, lrow, half);
+#pragma unroll
+    for (int r = 0; r < RB; ++r) split_epilogue<NT>(p, acc[r], m0, n0, wave * RB + r, lrow, half, SBM * RB);
 }
 
 // w (fp32, [rows][K], K contiguous) -> planes[NP][rows][K] bf16, w = sum of the planes up to 2^-24 relative
@@ -615,15 +638,26 @@ bool conv2d_split_eligible(const ConvArgs& a) {
 }
 
 template <int NP, bool F16>
-static void launch_split(const SplitP& p, int nt, hipStream_t s, bool ad) {
+static void launch_split(const SplitP& p, int nt, hipStream_t s, int ad) {   // ad: 0 = staged, 1 / 2 = A-direct with RB row blocks
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    if (ad == 2) {
+        switch (nt) {
+            case 1: hipLaunchKernelGGL((conv_split_ad_kernel<1, NP, F16, 2>), grid, dim3(256), 0, s, p); break;
+            case 2: hipLaunchKernelGGL((conv_split_ad_kernel<2, NP, F16, 2>), grid, dim3(256), 0, s, p); break;
+            case 3: hipLaunchKernelGGL((conv_split_ad_kernel<3, NP, F16, 2>), grid, dim3(256), 0, s, p); break;
+            case 4: hipLaunchKernelGGL((conv_split_ad_kernel<4, NP, F16, 2>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((conv_split_ad_kernel<5, NP, F16, 2>), grid, dim3(256), 0, s, p); break;
+        }
+        check_launch("conv_split_ad2");
+        return;
+    }
     if (ad) {
         switch (nt) {
-            case 1: hipLaunchKernelGGL((conv_split_ad_kernel<1, NP, F16>), grid, dim3(256), 0, s, p); break;
-            case 2: hipLaunchKernelGGL((conv_split_ad_kernel<2, NP, F16>), grid, dim3(256), 0, s, p); break;
-            case 3: hipLaunchKernelGGL((conv_split_ad_kernel<3, NP, F16>), grid, dim3(256), 0, s, p); break;
-            case 4: hipLaunchKernelGGL((conv_split_ad_kernel<4, NP, F16>), grid, dim3(256), 0, s, p); break;
-            default: hipLaunchKernelGGL((conv_split_ad_kernel<5, NP, F16>), grid, dim3(256), 0, s, p); break;
+            case 1: hipLaunchKernelGGL((conv_split_ad_kernel<1, NP, F16, 1>), grid, dim3(256), 0, s, p); break;
+            case 2: hipLaunchKernelGGL((conv_split_ad_kernel<2, NP, F16, 1>), grid, dim3(256), 0, s, p); break;
+            case 3: hipLaunchKernelGGL((conv_split_ad_kernel<3, NP, F16, 1>), grid, dim3(256), 0, s, p); break;
+            case 4: hipLaunchKernelGGL((conv_split_ad_kernel<4, NP, F16, 1>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((conv_split_ad_kernel<5, NP, F16, 1>), grid, dim3(256), 0, s, p); break;
         }
         check_launch("conv_split_ad");
         return;
@@ -659,9 +693,19 @@ void conv2d_split(const ConvArgs& a, int nt, hipStream_t s) {
     p.w_plane_bytes = (unsigned)((int64_t)a.Cout * p.Ktot * 2);
     p.ovf = a.ovf;
     p.w_bytes = p.w_plane_bytes * 3u;   // planes are always stored 3 deep; bf16x3 reads the first two
-    // A-direct pays for the 3-piece mode on the large layers (+6 % on the 256^2/128^2/64^2 convs); the 2-piece mode and
-    // the small-M layers are faster with both operands staged (tools/bench_conv.py 11 31 10 30)
-    const bool ad = a.variant == 30 || (a.variant != 31 && np == 3 && (int64_t)p.tiles_m * p.tiles_n >= 512);
+    // Structure by measurement (tools/bench_conv.py 21 31 41 20 30 40 12 42, batch-16 layer shapes, TF/s of fp32-equivalent
+    // work, staged / A-direct 128-row / A-direct 256-row):
+    //   bf16x6  M >= 16384: 196-202 / 217-226 / 224-237    M = 4096: 131-156 / 160-175 / 164-182    M = 1024: 65 / 90 / 63
+    //   bf16x3  M >= 16384: 322-344 / 340-364 / 373-413    M = 4096: 224-259 / 195-239 / 209-255    M = 1024: 81 / 110 / 64
+    //   f16x3   M >= 16384: 302-331 /    -    / 331-365    M = 4096: 226-261 /    -    / 189-222
+    int ad;
+    if (a.variant == 30) ad = 1;
+    else if (a.variant == 31) ad = 0;
+    else if (a.variant == 32) ad = 2;
+    else if (np == 3) ad = p.M >= 4096 ? 2 : 1;
+    else if (a.precision == PREC_F16X3) ad = p.M >= 16384 ? 2 : 0;
+    else ad = p.M >= 16384 ? 2 : (p.M >= 4096 ? 0 : 1);
+    if (ad == 2) p.tiles_m = cdiv(p.M, 2 * SBM);   // 256-row block tile, one workgroup per CU
     if (a.precision == PREC_F16X3)
         launch_split<2, true>(p, nt, s, ad);
     else if (np == 2)

@@ -224,8 +224,9 @@ int dsd_block_forward(dsd_handle* h, const float* x, int B, int C, int H, int W,
 int dsd_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
                   int ks, int stride, int upsample, const float* emb, const float* res, float* y, void* stream);
 /* Same with an explicit arithmetic mode: 0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6 (fp32 operands split into bf16 pieces,
- * fp32 accumulation; conv_split.hip).  Shapes the split kernel cannot take fall back to fp32.  OR-ing 16 / 32 into
- * `precision` forces the A-direct / fully staged kernel structure (tests); otherwise the library chooses. */
+ * fp32 accumulation; conv_split.hip).  Shapes the split kernel cannot take fall back to fp32.  OR-ing 16 / 32 / 64
+ * into `precision` forces the A-direct / fully staged / 256-row A-direct kernel structure (tests); otherwise the library
+ * chooses. */
 int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
                        int ks, int stride, int upsample, const float* emb, const float* res, int precision, float* y,
                        void* stream);

@@ -79,7 +79,7 @@ def test_conv2d_vs_torch_cpu(ops, case, prec):
     assert rel_l2(ops.to_nchw(y), ref) < PREC_TOL[prec]
 
 
-@pytest.mark.parametrize("structure", ["adirect", "staged"])
+@pytest.mark.parametrize("structure", ["adirect", "adirect256", "staged"])
 @pytest.mark.parametrize("prec", ["bf16x6", "f16x3", "bf16x3"])
 def test_conv2d_split_structures(ops, prec, structure):
     """Both kernel structures of the split-bf16 convolution (the library picks per shape) on every eligible case,
@@ -113,7 +113,7 @@ def test_conv2d_split_extreme_magnitudes(ops):
     w[:8] *= 1e-10
     ref = F.conv2d(x.double(), w.double(), None, padding=1)
     for prec in ("bf16x6", "bf16x3"):
-        for structure in ("staged", "adirect"):
+        for structure in ("staged", "adirect", "adirect256"):
             y = ops.conv2d(cu(ops.to_nhwc(x)), cu(w), None, precision=prec, structure=structure)
             assert bool(torch.isfinite(y).all())
             assert rel_l2(ops.to_nchw(y), ref) < PREC_TOL[prec], (prec, structure)
