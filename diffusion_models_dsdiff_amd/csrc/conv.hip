@@ -527,13 +527,12 @@ static int pick_nt(int Cout, int tiles_m, int precision) {
     return best;
 }
 
-// split-bf16 arithmetic requested and usable for this problem?  Grids of at most one block per CU are latency-bound
-// and measurably faster on the fp32 kernel (8x8 layers at batch 16: 0.195 ms vs 0.275 ms), so those stay fp32.
+// split-bf16 arithmetic requested and usable for this problem?  (Until the A-direct kernel was software-pipelined, grids
+// of at most one block per CU were faster on the fp32 kernel and stayed there; now the 128-row A-direct kernel ties it in
+// bf16x6 and beats it in the 3-product modes on those layers — tools/bench_conv.py 0 31 30 with DSD_SHAPES=small.)
 static int effective_precision(const ConvArgs& a, int tiles_m) {
+    (void)tiles_m;
     if (a.precision == PREC_F32 || !conv2d_split_eligible(a)) return PREC_F32;
-    if (a.variant >= 30 && a.variant <= 32) return a.precision;   // structure forced by a test
-    const int nt = pick_nt(a.Cout, tiles_m, a.precision);
-    if ((int64_t)tiles_m * cdiv(cdiv(a.Cout, 32), nt) <= 256) return PREC_F32;
     return a.precision;
 }
 

@@ -8,11 +8,16 @@
 // at 6 (resp. 3) v_mfma_f32_32x32x16_bf16 per 16 k instead of 8 v_mfma_f32_32x32x2_f32: 2.67x (5.3x) fewer matrix-pipe
 // cycles.  Weights are split once at upload (split_weights); activations are split while they are staged into LDS.
 //
-// Three structures were measured (tools/bench_conv.py; 16x256x256x320->320, bf16x6 / bf16x3 TF/s of fp32-equivalent work):
-// both operands staged through LDS 188 / 319 (conv_split_kernel); activations read straight into registers 199 / 322
-// (conv_split_ad_kernel, used for bf16x6 on the large layers); producer/consumer wave specialisation with two LDS stages
-// 165 / 326 (removed).  PMC: clock 1.88 GHz under bf16 load, 6 x 195 = 1.17 PF/s issued = 47 % of the nominal bf16 peak,
-// in the range hand-tuned bf16 GEMMs reach on this part (MI355X_MICROARCH.md "DVFS give-back").
+// Structures measured (tools/bench_conv.py, tools/ab_conv.sh; 16x256x256x320->320, bf16x6 / bf16x3 TF/s of fp32-equivalent
+// work): both operands staged through LDS 196 / 333 (conv_split_kernel); activations read straight into registers
+// (conv_split_ad_kernel): single LDS stage, two barriers per k-tile 199 / 322 -> two weight stages, one barrier 205 ->
+// staging software-pipelined into the MFMA stream, branch-free loop body 216-222 / 350 -> 256-row block tile, one workgroup
+// per CU 221-229 / 378-384 (the default on the large layers).  Measured and removed: producer/consumer wave specialisation
+// 165 / 326; a schedule pinned group by group without the pipelining 196; the 256-row kernel on the 16x16x32 MFMA shape
+// 223 / 355 (no clock gain here, MI355X_MICROARCH.md "DVFS give-back" 7 notwithstanding); a third weight stage that moves
+// the first fragment read of a tile in front of the barrier 220 / 355.
+// PMC (profiles/r01_pmc.json): MFMA pipe busy 71 %, clock 1.80 GHz, no LDS bank conflicts; 6 x 226 = 1.36 PF/s issued =
+// 54 % of the nominal bf16 peak, 72 % of what the matrix pipes deliver at the clock the chip holds under this load.
 //
 // Tiling is the fp32 kernel's (conv.hip): 256 threads, 128 x 32*NT x 32 block tile, wave = 32 rows x NT column tiles,
 // buffer loads with hardware range checks, register prefetch of the next tile, fused bias/embedding/residual epilogue.
