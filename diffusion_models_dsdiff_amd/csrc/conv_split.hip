@@ -491,13 +491,17 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
     // counters of the next tile to LOAD, branch-free (scalar selects): the loop body below is one basic block so that the
     // compiler can interleave the staging work with the MFMAs.  Past the last tile the counters run on harmlessly: the
     // loads are range-checked by the buffer resources (or hit valid activations) and their data is never multiplied.
+    // k-tile order: the filter taps are the INNER loop and the 32-channel chunk the outer one, so nine consecutive tiles
+    // re-read the same 128-byte lines of a pixel neighbourhood while they are hot in L2 instead of coming back to them
+    // a whole channel sweep later (HBM reads per launch 3.9 GB -> see profiles/; less HBM traffic also means a higher
+    // clock under the MFMA load, MI355X_MICROARCH.md "DVFS give-back").
     auto advance = [&]() {
-        const bool wrap = cc + 1 == p.cchunks;
-        cc = wrap ? 0 : cc + 1;
-        tap += wrap ? 1 : 0;
-        const bool wrapw = wrap && (kw + 1 == p.ks);
-        kw = wrap ? (wrapw ? 0 : kw + 1) : kw;
-        kh += wrapw ? 1 : 0;
+        const bool wrapw = kw + 1 == p.ks;
+        const bool wraph = wrapw && (kh + 1 == p.ks);
+        kw = wrapw ? 0 : kw + 1;
+        kh = wrapw ? (wraph ? 0 : kh + 1) : kh;
+        cc += wraph ? 1 : 0;
+        tap = kh * p.ks + kw;
     };
     auto load_a = [&](int r) {
         const int soff_a = __builtin_amdgcn_readfirstlane(cc * (SBK * 4));   // uniform by construction; keeps it scalar
