@@ -466,6 +466,9 @@ int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride,
         split_weights(w.as<float>(), (int64_t)nw, 3, planes.p, s, a.precision == PREC_F16X3);
         a.w_split = planes.p;
     }
+    Tmp scratch(conv2d_scratch_bytes(a));
+    a.scratch = scratch.as<float>();
+    a.scratch_bytes = conv2d_scratch_bytes(a);
     conv2d(a, s);  // warm-up
     hipEvent_t e0, e1;
     DSD_HIP(hipEventCreate(&e0));
@@ -505,6 +508,9 @@ int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float
         if (precision & 32) a.variant = 31;   // force the staged structure
         if (precision & 64) a.variant = 32;   // force the 256-row A-direct tile
     }
+    Tmp scratch(conv2d_scratch_bytes(a));
+    a.scratch = scratch.as<float>();
+    a.scratch_bytes = conv2d_scratch_bytes(a);
     conv2d(a, s);
     int flag = 0;
     DSD_HIP(hipMemcpyAsync(&flag, ovf.p, sizeof(int), hipMemcpyDeviceToHost, s));

@@ -536,6 +536,16 @@ static int effective_precision(const ConvArgs& a, int tiles_m) {
     return a.precision;
 }
 
+size_t conv2d_scratch_bytes(const ConvArgs& a) {
+    if (a.precision == PREC_F32 || a.Cin % 32 != 0 || a.Cin % 4 != 0) return 0;
+    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
+    const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
+    const int64_t M = (int64_t)a.N * OH * OW;
+    const int tm = cdiv(M, BM);
+    const int ks = conv2d_split_ksplit(a, pick_nt(a.Cout, tm, a.precision));
+    return ks > 1 ? (size_t)ks * M * a.Cout * sizeof(float) : 0;
+}
+
 const char* conv2d_variant(const ConvArgs& a) {
     const int Ktot = a.ks * a.ks * a.Cin;
     if (a.Cin % 4 != 0 || Ktot < 32) return (a.Cout % 4 == 0 && (size_t)Ktot * a.Cout * 4 <= 60 * 1024) ? "conv_direct_lds" : "conv_scalar";

@@ -53,6 +53,8 @@ struct SplitP {
     int M, Ktot, cchunks, IHg, IWg, tiles_m, tiles_n, ohw;
     unsigned x_bytes, w_bytes, w_plane_bytes;
     int* ovf;   // f16x3 only: set to 1 when an operand magnitude exceeds the fp16 range (caller reports it)
+    int ksplit;       // split-K: the k-tiles are divided over ksplit workgroups per output tile (A-direct 128-row kernel)
+    float* partial;   // [ksplit][M][Cout] raw partial sums, reduced (+ bias / embedding / residual) by splitk_reduce_kernel
 };
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -398,6 +400,9 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         const int cpx = nwg >> 3;
         if (L < (cpx << 3)) L = (L & 7) * cpx + (L >> 3);
     }
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int chunk = L / ntiles;   // split-K chunk of this workgroup (0 when ksplit == 1)
+    L -= chunk * ntiles;
     const int tile_n = L % p.tiles_n;
     const int tile_m = L / p.tiles_n;
     const int m0 = tile_m * (SBM * RB);
@@ -486,8 +491,12 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
     // unit's weight fragments (sched_barriers pin that order: left alone, the compiler waits on LDS in front of most MFMAs).
     constexpr int U = 2 * NT;
     constexpr int NTASK = 4 * RB;   // split4 calls per tile
-    const int KT = p.ks * p.ks * p.cchunks;
-    int kh = 0, kw = 0, cc = 0, tap = 0;
+    const int KT_all = p.ks * p.ks * p.cchunks;
+    const int kt_first = (int)((int64_t)chunk * KT_all / p.ksplit);
+    const int KT = (int)((int64_t)(chunk + 1) * KT_all / p.ksplit) - kt_first;   // k-tiles of this workgroup
+    const int taps = p.ks * p.ks;
+    int cc = kt_first / taps, tap = kt_first - cc * taps;
+    int kh = tap / p.ks, kw = tap - kh * p.ks;
     // counters of the next tile to LOAD, branch-free (scalar selects): the loop body below is one basic block so that the
     // compiler can interleave the staging work with the MFMAs.  Past the last tile the counters run on harmlessly: the
     // loads are range-checked by the buffer resources (or hit valid activations) and their data is never multiplied.
@@ -504,7 +513,9 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         tap = kh * p.ks + kw;
     };
     auto load_a = [&](int r) {
-        const int soff_a = __builtin_amdgcn_readfirstlane(cc * (SBK * 4));   // uniform by construction; keeps it scalar
+        // uniform by construction (readfirstlane keeps it scalar); clamped so that the two look-ahead tiles past the end
+        // of the k-loop re-read the last channel chunk instead of the bytes behind the pixel
+        const int soff_a = __builtin_amdgcn_readfirstlane(min(cc, p.cchunks - 1) * (SBK * 4));
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             ra[r][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[r][i], soff_a, 0));
@@ -533,7 +544,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
     bf16x8 af[2][RB][NP];   // A fragments of the current tile (both k-steps), in registers
     bf16x8 afn1[RB][NP];    // second k-step of the next tile (af[1] is live until the last unit)
     // prologue: tile 0 -> af / LDS stage 0, tile 1 -> ra / rb in flight
-    tap_offsets(0, 0);
+    tap_offsets(kh, kw);
 #pragma unroll
     for (int r = 0; r < RB; ++r) load_a(r);
     load_b();
@@ -607,8 +618,43 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
 #pragma unroll
             for (int q = 0; q < NP; ++q) af[1][r][q] = afn1[r][q];
     }
+    if (p.ksplit > 1) {   // raw partial sums; bias / embedding / residual are added once, by the reduction
+        SplitP q = p;
+        q.y = p.partial + (int64_t)chunk * p.M * p.Cout;
+        q.bias = q.emb = q.res = nullptr;
+        q.out_nchw = 0;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) split_epilogue<NT>(q, acc[r], m0, n0, wave * RB + r, lrow, half, SBM * RB);
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < RB; ++r) split_epilogue<NT>(p, acc[r], m0, n0, wave * RB + r, lrow, half, SBM * RB);
+}
+
+// y = sum over the k-chunks of the partial tiles (fixed order: deterministic) + bias + embedding + residual
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int Cout,
+                                                            const float* __restrict__ bias, const float* __restrict__ emb,
+                                                            int emb_stride, int ohw, const float* __restrict__ res,
+                                                            float* __restrict__ y, int out_nchw) {
+    const int64_t total4 = (int64_t)M * Cout / 4;
+    const int64_t plane = (int64_t)M * Cout;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t e = i * 4;
+        const int m = (int)(e / Cout), n = (int)(e - (int64_t)m * Cout);
+        f32x4 v = *reinterpret_cast<const f32x4*>(partial + e);
+        for (int c = 1; c < S; ++c) v += *reinterpret_cast<const f32x4*>(partial + c * plane + e);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        const int nb = m / ohw;
+        if (emb) v += *reinterpret_cast<const f32x4*>(emb + (int64_t)nb * emb_stride + n);
+        if (res) v += *reinterpret_cast<const f32x4*>(res + e);
+        if (out_nchw) {
+            const int r = m - nb * ohw;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) y[((int64_t)nb * Cout + n + k) * ohw + r] = v[k];
+        } else {
+            *reinterpret_cast<f32x4*>(y + e) = v;
+        }
+    }
 }
 
 // w (fp32, [rows][K], K contiguous) -> planes[NP][rows][K] bf16, w = sum of the planes up to 2^-24 relative
@@ -648,7 +694,7 @@ bool conv2d_split_eligible(const ConvArgs& a) {
 
 template <int NP, bool F16>
 static void launch_split(const SplitP& p, int nt, hipStream_t s, int ad) {   // ad: 0 = staged, 1 / 2 = A-direct with RB row blocks
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (ad == 1 ? p.ksplit : 1)));
     if (ad == 2) {
         switch (nt) {
             case 1: hipLaunchKernelGGL((conv_split_ad_kernel<1, NP, F16, 2>), grid, dim3(256), 0, s, p); break;
@@ -681,6 +727,31 @@ static void launch_split(const SplitP& p, int nt, hipStream_t s, int ad) {   // 
     check_launch("conv_split");
 }
 
+// structure of the split-precision convolution for a problem (0 staged, 1 / 2 A-direct with 128 / 256-row tiles)
+static int split_structure(const ConvArgs& a, int M) {
+    if (a.variant == 30) return 1;
+    if (a.variant == 31) return 0;
+    if (a.variant == 32) return 2;
+    if (a.precision == PREC_BF16X6) return M >= 4096 ? 2 : 1;
+    if (a.precision == PREC_F16X3) return M >= 16384 ? 2 : 0;
+    return M >= 16384 ? 2 : (M >= 4096 ? 0 : 1);
+}
+
+// Split-K: a layer whose output has fewer tiles than the chip has CUs (8x8 and 16x16 maps at small batch) runs its long
+// k-loop (up to 540 tiles) serially in a handful of workgroups.  The 128-row A-direct kernel then divides the k-tiles
+// over `ksplit` workgroups per output tile and a second kernel adds the partial tiles in a fixed order.
+int conv2d_split_ksplit(const ConvArgs& a, int nt) {
+    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
+    const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
+    const int64_t M = (int64_t)a.N * OH * OW;
+    static const bool off = getenv("DSD_NO_SPLITK") != nullptr;   // experiments only
+    if (off || M >= 4096 || split_structure(a, (int)M) != 1 || a.Cout % 4 != 0) return 1;
+    const int blocks = cdiv((int)M, SBM) * cdiv(a.Cout, nt * 32);
+    const int KT = a.ks * a.ks * (a.Cin / SBK);
+    if (blocks > 128 || KT < 32) return 1;
+    return std::max(1, std::min(std::min(16, 512 / blocks), KT / 8));
+}
+
 void conv2d_split(const ConvArgs& a, int nt, hipStream_t s) {
     SplitP p{};
     p.x = a.x; p.w = a.w_split; p.bias = a.bias; p.emb = a.emb; p.res = a.res; p.y = a.y;
@@ -707,20 +778,28 @@ void conv2d_split(const ConvArgs& a, int nt, hipStream_t s) {
     //   bf16x6  M >= 16384: 196-202 / 217-226 / 224-237    M = 4096: 131-156 / 160-175 / 164-182    M = 1024: 65 / 90 / 63
     //   bf16x3  M >= 16384: 322-344 / 340-364 / 373-413    M = 4096: 224-259 / 195-239 / 209-255    M = 1024: 81 / 110 / 64
     //   f16x3   M >= 16384: 302-331 /    -    / 331-365    M = 4096: 226-261 /    -    / 189-222
-    int ad;
-    if (a.variant == 30) ad = 1;
-    else if (a.variant == 31) ad = 0;
-    else if (a.variant == 32) ad = 2;
-    else if (np == 3) ad = p.M >= 4096 ? 2 : 1;
-    else if (a.precision == PREC_F16X3) ad = p.M >= 16384 ? 2 : 0;
-    else ad = p.M >= 16384 ? 2 : (p.M >= 4096 ? 0 : 1);
+    const int ad = split_structure(a, p.M);
     if (ad == 2) p.tiles_m = cdiv(p.M, 2 * SBM);   // 256-row block tile, one workgroup per CU
+    p.ksplit = 1;
+    if (ad == 1 && a.scratch) {
+        const int ks = conv2d_split_ksplit(a, nt);
+        if (ks > 1 && (size_t)ks * p.M * a.Cout * sizeof(float) <= a.scratch_bytes) {
+            p.ksplit = ks;
+            p.partial = a.scratch;
+        }
+    }
     if (a.precision == PREC_F16X3)
         launch_split<2, true>(p, nt, s, ad);
     else if (np == 2)
         launch_split<2, false>(p, nt, s, ad);
     else
         launch_split<3, false>(p, nt, s, ad);
+    if (p.ksplit > 1) {
+        const int64_t total4 = (int64_t)p.M * a.Cout / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>((total4 + 255) / 256, 2048)), dim3(256), 0, s,
+                           p.partial, p.ksplit, p.M, a.Cout, a.bias, a.emb, a.emb_stride, p.ohw, a.res, a.y, a.out_nchw);
+        check_launch("splitk_reduce");
+    }
 }
 
 }  // namespace dsd

@@ -24,6 +24,8 @@ struct ConvArgs {
     int precision = 0;          // PREC_F32 | PREC_BF16X3 | PREC_BF16X6 (conv_split.hip)
     const void* w_split = nullptr;  // [3][Cout][ks*ks*Cin] bf16 pieces of w (needed for the split precisions)
     int* ovf = nullptr;             // device flag set by the f16x3 kernels when an operand exceeds the fp16 range
+    float* scratch = nullptr;       // split-K partial sums (conv2d_scratch_bytes() bytes); without it small grids run unsplit
+    size_t scratch_bytes = 0;
 };
 enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16X6 = 2, PREC_F16X3 = 3 };
 void conv2d(ConvArgs a, hipStream_t s);
@@ -32,6 +34,8 @@ void split_weights(const float* w, int64_t n, int np, void* planes, hipStream_t 
 bool conv2d_split_eligible(const ConvArgs& a);
 void conv2d_split(const ConvArgs& a, int nt, hipStream_t s);
 double conv2d_flops(const ConvArgs& a);
+size_t conv2d_scratch_bytes(const ConvArgs& a);   // workspace conv2d() can use for these arguments (0 = none)
+int conv2d_split_ksplit(const ConvArgs& a, int nt);   // k-chunks the split-precision kernel would run this problem in
 const char* conv2d_variant(const ConvArgs& a);   // name of the kernel conv2d() will launch for these arguments
 void pack_ohwi(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, hipStream_t s);
 

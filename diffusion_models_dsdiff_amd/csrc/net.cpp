@@ -482,6 +482,8 @@ struct Builder {
             a.precision = hd->precision;
             a.ovf = f16 ? hd->ovf : nullptr;
         }
+        const size_t skb = conv2d_scratch_bytes(a);            // split-K partial tiles of the small-grid layers
+        const size_t skoff = skb ? alloc_raw(skb) : 0;
         const size_t xoff = x.off, yoff = y.off, roff = res ? res->off : 0;
         const bool has_res = res != nullptr;
         EmbRef e;
@@ -505,9 +507,14 @@ struct Builder {
                 c.emb_stride = e.stride;
             }
             if (has_res) c.res = reinterpret_cast<const float*>(h->arena + roff);
+            if (skb) {
+                c.scratch = reinterpret_cast<float*>(h->arena + skoff);
+                c.scratch_bytes = skb;
+            }
             conv2d(c, s);
         }, 1, conv2d_variant(a), conv2d_flops(a),
            4.0 * ((double)x.n * x.h * x.w * x.c + (double)cout * x.c * ks * ks + (double)x.n * OH * OW * cout * (has_res ? 2 : 1)));
+        if (skb) release_raw(skoff, skb);
         return y;
     }
 

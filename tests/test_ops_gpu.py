@@ -57,6 +57,8 @@ CONV_CASES = [
     (1, 4, 4, 6, 5, 3, 2, False),         # scalar fallback
     (2, 64, 64, 128, 96, 3, 1, False),
     (2, 128, 128, 64, 320, 3, 1, False),  # >= 512 tiles: the shape class where the library itself picks the A-direct structure
+    (1, 8, 8, 960, 960, 3, 1, False),     # batch-1 bottleneck layer: 30 output tiles, 270 k-tiles -> split-K x16
+    (1, 8, 8, 320, 100, 3, 1, False),     # split-K x11 with ragged M (64 rows) and ragged N (100 columns)
 ]
 
 
