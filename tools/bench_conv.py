@@ -13,6 +13,10 @@ SHAPES = [  # N, H, W, Cin, Cout, ks, stride
 if os.environ.get("DSD_SHAPES") == "small":
     SHAPES = [(16, 16, 16, 960, 960, 3, 1), (16, 8, 8, 960, 960, 3, 1), (16, 8, 8, 1920, 960, 3, 1), (16, 16, 16, 960, 2880, 1, 1),
               (16, 8, 8, 960, 480, 1, 1), (16, 8, 8, 2880, 960, 1, 1), (16, 16, 16, 1920, 960, 1, 1), (16, 32, 32, 640, 1920, 1, 1)]
+if os.environ.get("DSD_SHAPES") == "b1":   # batch-1 layer shapes (few output tiles)
+    SHAPES = [(1, 256, 256, 320, 320, 3, 1), (1, 128, 128, 320, 320, 3, 1), (1, 128, 128, 640, 320, 3, 1), (1, 64, 64, 640, 640, 3, 1),
+              (1, 64, 64, 1280, 640, 3, 1), (1, 32, 32, 640, 640, 3, 1), (1, 32, 32, 1280, 640, 3, 1), (1, 16, 16, 960, 960, 3, 1),
+              (1, 8, 8, 960, 960, 3, 1), (2, 64, 64, 640, 640, 3, 1), (4, 32, 32, 640, 640, 3, 1)]
 variants = [int(v) for v in sys.argv[1:]] or [0, 1]
 for shp in SHAPES:
     row = []
