@@ -344,3 +344,28 @@ def test_full_size_dpm_properties(full_model):
     assert rel_l2(run(xT[1:], cond[1:]), y[1:]) < 1e-5
     z = run(xT, cond, denoise_to_zero=True)                                # final x = thresholded data prediction
     assert float(z.abs().max()) <= 1.0
+
+
+def test_full_size_full_length_chain_default_vs_exact_fp32(full_model):
+    """The whole BASELINE job for one slice — 981.5 M-parameter network, 256x256, all 1000 DDPM steps, Philox noise from
+    one seed — in the default arithmetic (bf16x6) and in the exact-fp32 MFMA mode (an fp32 fma chain, pinned against the
+    oracle at 64x64 above): the two sampled images must agree to the north-star tolerance (1e-4 rel-L2), and a repeat of
+    the default run must be bit-identical."""
+    from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
+    from diffusion_models_dsdiff_amd._sched import run_device_loop
+    m, _, _ = full_model
+    d = create_gaussian_diffusion(steps=1000, parameterization="v")
+    sched = d._schedule(False, 0.0, True)
+    shape = (1, 1, 256, 256)
+    cond, xT = cond_image_(shape, 61).cuda(), randn(shape, 62).cuda()
+    out = {}
+    for prec in ("bf16x6", "f32"):
+        m.set_precision(prec)
+        out[prec] = run_device_loop(m, sched, xT, cond, seed=77)
+        assert bool(torch.isfinite(out[prec]).all()) and float(out[prec].abs().max()) <= 1.0 + 1e-6   # clip_denoised at t = 0
+    m.set_precision("bf16x6")
+    err = rel_l2(out["bf16x6"], out["f32"])
+    print(f"full-size 1000-step chain, bf16x6 vs exact fp32: rel-L2 {err:.3e}")
+    assert err < 1e-4
+    assert torch.equal(run_device_loop(m, sched, xT, cond, seed=77, first_step=0, n_steps=25),
+                       run_device_loop(m, sched, xT, cond, seed=77, first_step=0, n_steps=25))
