@@ -512,7 +512,7 @@ struct Builder {
                 c.scratch_bytes = skb;
             }
             conv2d(c, s);
-        }, 1, conv2d_variant(a), conv2d_flops(a),
+        }, skb ? 2 : 1, conv2d_variant(a), conv2d_flops(a),
            4.0 * ((double)x.n * x.h * x.w * x.c + (double)cout * x.c * ks * ks + (double)x.n * OH * OW * cout * (has_res ? 2 : 1)));
         if (skb) release_raw(skoff, skb);
         return y;
