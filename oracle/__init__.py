@@ -12,7 +12,7 @@ Rules (see DESIGN.md "Oracle"):
     has no CPU fallback: it raises when the HIP library is missing.
   * Parity status: PINNED.  ``tests/golden/*.npz`` were produced by importing
     the reference itself on CPU in the build container
-    (``tools/gen_golden.py``); ``tests/test_oracle_golden.py`` checks the oracle
+    (``tests/golden/gen_golden.py``); ``tests/test_oracle_golden.py`` checks the oracle
     against every one of them (integer maps bit-exact, tables to float64/fp32
     equality, network outputs to <= 2e-6 rel-L2).
 """

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by importing the REFERENCE on CPU (build container only).
 
-    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
 
 The reference never travels to the GPU box; only the small data fixtures written here do.
 Weights are not stored: each fixture stores (names, shapes, seed) and the tests regenerate them
@@ -16,7 +16,7 @@ import sys
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
 REF = os.environ.get("DSD_REFERENCE", "/root/reference")
 sys.path.insert(0, REF)
@@ -24,7 +24,7 @@ sys.dont_write_bytecode = True
 
 from oracle.synth import synth_params, randn, cond_image  # noqa: E402
 
-OUT = os.path.join(REPO, "tests", "golden")
+OUT = os.path.dirname(os.path.abspath(__file__))
 os.makedirs(OUT, exist_ok=True)
 torch.set_grad_enabled(False)
 torch.set_num_threads(8)

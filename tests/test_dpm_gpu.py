@@ -1,5 +1,5 @@
 """DPM-Solver(++) multistep parity (GPU): dsd_sample_dpm / dsd_op_dpm_step / dsd_op_dpm_threshold through the reference's
-call signatures vs fixtures produced by the reference's own solver (tests/golden/dpm.npz, tools/gen_golden.py::gen_dpm)
+call signatures vs fixtures produced by the reference's own solver (tests/golden/dpm.npz, tests/golden/gen_golden.py::gen_dpm)
 and vs the oracle (oracle/dpm.py).  Selection (quantile) and the post-network arithmetic are bit-exact; whole sampled
 images carry the network's fp32 tolerance, rel-L2 <= 1e-4 (BASELINE.json north_star), measured ~1e-6."""
 import ctypes as C

@@ -1,4 +1,4 @@
-"""Pins the CPU oracle against fixtures produced by the reference itself (tools/gen_golden.py).
+"""Pins the CPU oracle against fixtures produced by the reference itself (tests/golden/gen_golden.py).
 
 Integer maps: bit-exact.  float64 tables: exact (same numpy expressions) or <=1e-15 rel.
 fp32 network outputs: rel-L2 <= 2e-6 (same ATen kernels, association differs only in my restated

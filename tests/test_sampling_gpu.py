@@ -1,5 +1,5 @@
 """Sampling-loop parity (GPU): dsd_sample through the reference call signatures vs fixtures produced by the
-reference's own loops (tools/gen_golden.py) and vs the oracle.  Tolerance: rel-L2 <= 1e-4 on the final fp32 image
+reference's own loops (tests/golden/gen_golden.py) and vs the oracle.  Tolerance: rel-L2 <= 1e-4 on the final fp32 image
 (BASELINE.json north_star); measured values are ~1e-6."""
 import json
 

@@ -27,7 +27,7 @@ def rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-# ---- DPM-Solver(++) cases of tests/golden/dpm.npz (tools/gen_golden.py::gen_dpm) -------------------------------------
+# ---- DPM-Solver(++) cases of tests/golden/dpm.npz (tests/golden/gen_golden.py::gen_dpm) -------------------------------------
 # key -> (betas source, model_type, keyword arguments of DPM_Solver(...).sample / oracle.dpm.dpm_multistep)
 DPM_CASES = {
     "A_dpm_20": (("A", "linear", "20"), "noise", dict(steps=20, order=2, skip_type="logSNR", thresholding=True,
