@@ -542,7 +542,9 @@ size_t conv2d_scratch_bytes(const ConvArgs& a) {
     const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
     const int64_t M = (int64_t)a.N * OH * OW;
     const int tm = cdiv(M, BM);
-    const int ks = conv2d_split_ksplit(a, pick_nt(a.Cout, tm, a.precision));
+    if (effective_precision(a, tm) == PREC_F32) return 0;
+    int nt, ks;
+    conv2d_split_plan(a, pick_nt(a.Cout, tm, a.precision), &nt, &ks);
     return ks > 1 ? (size_t)ks * M * a.Cout * sizeof(float) : 0;
 }
 
@@ -557,7 +559,9 @@ const char* conv2d_variant(const ConvArgs& a) {
                                       {"", "conv_f16x3<1>", "conv_f16x3<2>", "conv_f16x3<3>", "conv_f16x3<4>", "conv_f16x3<5>"}};
     const int tm = cdiv((int64_t)a.N * OH * OW, BM);
     const int pr = effective_precision(a, tm);
-    return names[pr][pick_nt(a.Cout, tm, pr)];
+    int nt = pick_nt(a.Cout, tm, pr), ks = 1;
+    if (pr != PREC_F32) conv2d_split_plan(a, nt, &nt, &ks);
+    return names[pr][nt];
 }
 
 void conv2d(ConvArgs a, hipStream_t s) {
@@ -594,13 +598,16 @@ void conv2d(ConvArgs a, hipStream_t s) {
         return;
     }
     const int prec = effective_precision(a, p.tiles_m);
-    const int nt = pick_nt(a.Cout, p.tiles_m, prec);
-    p.tiles_n = cdiv(a.Cout, nt * 32);
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
+    int nt = pick_nt(a.Cout, p.tiles_m, prec);
     if (prec != PREC_F32) {
-        conv2d_split(a, nt, s);
+        int ks = 1, ad = 0;
+        // a caller without scratch (never the planned graph) gets the unsplit configuration
+        conv2d_split_plan(a, nt, &nt, &ks, &ad, a.scratch != nullptr);
+        conv2d_split(a, nt, ks, ad, s);
         return;
     }
+    p.tiles_n = cdiv(a.Cout, nt * 32);
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n));
     {
         // default path: buffer-load kernel when the operands are addressable with 32-bit byte offsets
         const int64_t xb = ((int64_t)(a.N - 1) * p.x_bs + (int64_t)a.H * a.W * a.Cin) * 4;

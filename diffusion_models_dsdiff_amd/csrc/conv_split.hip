@@ -25,6 +25,7 @@
 // 8 consecutive k = 16 B, slot (5*row + const) mod 16).
 #include "kernels.h"
 
+#include <cmath>
 #include <cstdlib>
 
 namespace dsd {
@@ -737,27 +738,62 @@ static int split_structure(const ConvArgs& a, int M) {
     return M >= 16384 ? 2 : (M >= 4096 ? 0 : 1);
 }
 
-// Split-K: a layer whose output has fewer tiles than the chip has CUs (8x8 and 16x16 maps at small batch) runs its long
-// k-loop (up to 540 tiles) serially in a handful of workgroups.  The 128-row A-direct kernel then divides the k-tiles
-// over `ksplit` workgroups per output tile and a second kernel adds the partial tiles in a fixed order.  Measured at
-// batch 1 (tools/bench_conv.py, DSD_SHAPES=b1): 8x8 960->960 0.096 -> 0.027 ms, whole step 52.0 -> 41.6 ms.
-int conv2d_split_ksplit(const ConvArgs& a, int nt) {
+// Split-K: a layer whose output has fewer tiles than the chip has CUs (8x8 and 16x16 maps, everything at small batch)
+// runs its long k-loop (up to 540 tiles) serially in a handful of workgroups, and the generic cost model then narrows the
+// N tile to get more workgroups, which re-reads and re-splits the activations once per N tile.  The A-direct kernels
+// instead divide the k-tiles over `ksplit` workgroups per output tile (a second kernel adds the partial tiles in a fixed
+// order), and tile width and split factor are chosen together from a small cycle model:
+//   workgroup = O + nt*E + ceil(KT/ksplit) * (A + nt*B)      time = max(1, workgroups / 256) * workgroup (+ reduction)
+// (in bf16x6 the 128-row / 256-row structure is part of the choice).
+// Measured (tools/bench_conv.py): batch 1, 8x8 960->960: 0.096 -> 0.027 ms, whole step 52.0 -> 40 ms; batch 16, 8x8
+// 960->960: 0.161 (nt 1, x2) -> 0.109 ms (nt 3, x6).  Grids that fill the chip anyway keep nt_default and ksplit = 1.
+void conv2d_split_plan(const ConvArgs& a, int nt_default, int* nt_out, int* ks_out, int* ad_out, bool allow_split) {
     const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
     const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
     const int64_t M = (int64_t)a.N * OH * OW;
-    static const bool off = getenv("DSD_NO_SPLITK") != nullptr;   // experiments only
-    if (off || M >= (1 << 20) || a.Cout % 4 != 0) return 1;
-    const int ad = split_structure(a, (int)M);
-    if (ad == 0) return 1;
-    const int blocks = cdiv((int)M, ad * SBM) * cdiv(a.Cout, nt * 32);
+    int ad0 = split_structure(a, (int)std::min<int64_t>(M, 1 << 30));
+    *nt_out = nt_default;
+    *ks_out = 1;
+    if (ad_out) *ad_out = ad0;
+    static const bool off = getenv("DSD_NO_SPLITK") != nullptr;      // experiments only
+    static const bool forced_nt = getenv("DSD_FORCE_NT") != nullptr;
+    if (off || !allow_split || M >= (1 << 20) || a.Cout % 4 != 0 || ad0 == 0) return;
+    const int t32 = cdiv(a.Cout, 32);
     const int KT = a.ks * a.ks * (a.Cin / SBK);
-    // resident workgroups the chip holds: 2 per CU on the 128-row tile, 1 per CU on the 256-row tile
-    const int want = ad == 1 ? 640 : 256, limit = ad == 1 ? 320 : 128;
-    if (blocks > limit || KT < 32) return 1;
-    return std::max(1, std::min(std::min(16, (want + blocks / 2) / blocks), KT / 8));
+    // only grids that leave CUs idle are re-planned; everything else keeps the measured structure and nt_default
+    if ((int64_t)cdiv((int)M, ad0 * SBM) * cdiv(t32, nt_default) > (ad0 == 1 ? 320 : 160) || KT < 32) return;
+    const bool free_structure = a.precision == PREC_BF16X6 && !(a.variant >= 30 && a.variant <= 32);
+    double best_t = 1e300;
+    for (int ad = 1; ad <= 2; ++ad) {
+        if (!free_structure && ad != ad0) continue;
+        const int tiles_m = cdiv((int)M, ad * SBM);
+        const double mf = (a.precision == PREC_BF16X6 ? 384.0 : 192.0) * ad;   // MFMA cycles per k-tile per 32 columns
+        const double fix = ad == 1 ? 700.0 : 1000.0;                            // per k-tile: activation loads, split, barrier
+        for (int nt = forced_nt ? nt_default : 5; nt >= (forced_nt ? nt_default : 1); --nt) {
+            const int blocks = tiles_m * cdiv(t32, nt);
+            for (int ks = 1; ks <= 16; ++ks) {
+                if (ks > 1 && KT / ks < 8) break;
+                if (ks > 1 && (int64_t)blocks * ks > 768) break;
+                const double wg = 3000.0 + nt * 600.0 + cdiv(KT, ks) * (fix + nt * mf);
+                // a CU holds one 256-row workgroup or two 128-row ones.  Two residents of a small-M layer (weight streaming,
+                // latency-bound) overlap well; on mid-size M they compete for the matrix pipes and the second one buys
+                // nothing (measured: 8x8 960->960 x16: 480 workgroups 0.098 ms vs 240 0.125; 64x64 640->640 x1: 512
+                // workgroups 0.218 ms vs 256 0.154)
+                const double over = std::max(1.0, (double)blocks * ks / 256.0);
+                double t = (ad == 1 && M <= 2048 ? std::pow(over, 0.6) : over) * wg;
+                if (ks > 1) t += 9000.0 + (double)ks * M * a.Cout * 4.0 / 2.5e12 * 1.8e9;   // the reduction kernel
+                if (t < best_t * 0.999) {
+                    best_t = t;
+                    *nt_out = nt;
+                    *ks_out = ks;
+                    if (ad_out) *ad_out = ad;
+                }
+            }
+        }
+    }
 }
 
-void conv2d_split(const ConvArgs& a, int nt, hipStream_t s) {
+void conv2d_split(const ConvArgs& a, int nt, int ksplit, int ad, hipStream_t s) {
     SplitP p{};
     p.x = a.x; p.w = a.w_split; p.bias = a.bias; p.emb = a.emb; p.res = a.res; p.y = a.y;
     p.N = a.N; p.H = a.H; p.W = a.W; p.Cin = a.Cin; p.Cout = a.Cout; p.ks = a.ks; p.stride = a.stride;
@@ -783,15 +819,14 @@ void conv2d_split(const ConvArgs& a, int nt, hipStream_t s) {
     //   bf16x6  M >= 16384: 196-202 / 217-226 / 224-237    M = 4096: 131-156 / 160-175 / 164-182    M = 1024: 65 / 90 / 63
     //   bf16x3  M >= 16384: 322-344 / 340-364 / 373-413    M = 4096: 224-259 / 195-239 / 209-255    M = 1024: 81 / 110 / 64
     //   f16x3   M >= 16384: 302-331 /    -    / 331-365    M = 4096: 226-261 /    -    / 189-222
-    const int ad = split_structure(a, p.M);
     if (ad == 2) p.tiles_m = cdiv(p.M, 2 * SBM);   // 256-row block tile, one workgroup per CU
     p.ksplit = 1;
-    if (ad >= 1 && a.scratch) {
-        const int ks = conv2d_split_ksplit(a, nt);
-        if (ks > 1 && (size_t)ks * p.M * a.Cout * sizeof(float) <= a.scratch_bytes) {
-            p.ksplit = ks;
-            p.partial = a.scratch;
-        }
+    if (ad >= 1 && ksplit > 1) {
+        DSD_CHECK(a.scratch && (size_t)ksplit * p.M * a.Cout * sizeof(float) <= a.scratch_bytes,
+                  "conv2d: split-K x%d needs %zu bytes of scratch (conv2d_scratch_bytes), got %zu", ksplit,
+                  (size_t)ksplit * p.M * a.Cout * sizeof(float), a.scratch_bytes);
+        p.ksplit = ksplit;
+        p.partial = a.scratch;
     }
     if (a.precision == PREC_F16X3)
         launch_split<2, true>(p, nt, s, ad);

@@ -32,10 +32,12 @@ void conv2d(ConvArgs a, hipStream_t s);
 // conv_split.hip: fp32 operands as sums of bf16 pieces on the bf16 matrix cores
 void split_weights(const float* w, int64_t n, int np, void* planes, hipStream_t s, bool f16 = false, int* ovf = nullptr);
 bool conv2d_split_eligible(const ConvArgs& a);
-void conv2d_split(const ConvArgs& a, int nt, hipStream_t s);
+void conv2d_split(const ConvArgs& a, int nt, int ksplit, int structure, hipStream_t s);
 double conv2d_flops(const ConvArgs& a);
 size_t conv2d_scratch_bytes(const ConvArgs& a);   // workspace conv2d() can use for these arguments (0 = none)
-int conv2d_split_ksplit(const ConvArgs& a, int nt);   // k-chunks the split-precision kernel would run this problem in
+// N-tile width (in 32-column units) and split-K factor the split-precision path runs this problem with; nt_default is the
+// width the generic cost model (conv.hip pick_nt) would take
+void conv2d_split_plan(const ConvArgs& a, int nt_default, int* nt, int* ksplit, int* structure = nullptr, bool allow_split = true);
 const char* conv2d_variant(const ConvArgs& a);   // name of the kernel conv2d() will launch for these arguments
 void pack_ohwi(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, hipStream_t s);
 
