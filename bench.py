@@ -198,7 +198,7 @@ def main():
             if os.path.exists(pmc):
                 try:
                     want = {"f32": ("conv_mfma_buf_kernel", "<5>"), "bf16x6": ("conv_split", "<5, 3"),
-                            "bf16x3": ("conv_split", "<5, 2, false>"), "f16x3": ("conv_split", "<5, 2, true>")}[precision]
+                            "bf16x3": ("conv_split", "<5, 2, false"), "f16x3": ("conv_split", "<5, 2, true")}[precision]
                     best = 0.0
                     for kname, e in json.load(open(pmc)).items():   # the variant with the most time under PMC
                         if want[0] in kname and want[1] in kname and e.get("total_us_under_pmc", 0) > best:

@@ -24,6 +24,8 @@
 //   variant and an accumulator-interleaved MFMA order were tried and are not faster (142 / 127).
 #include "kernels.h"
 
+#include <string>
+
 #include <cstdlib>
 
 namespace dsd {
@@ -559,9 +561,15 @@ const char* conv2d_variant(const ConvArgs& a) {
                                       {"", "conv_f16x3<1>", "conv_f16x3<2>", "conv_f16x3<3>", "conv_f16x3<4>", "conv_f16x3<5>"}};
     const int tm = cdiv((int64_t)a.N * OH * OW, BM);
     const int pr = effective_precision(a, tm);
-    int nt = pick_nt(a.Cout, tm, pr), ks = 1;
-    if (pr != PREC_F32) conv2d_split_plan(a, nt, &nt, &ks);
-    return names[pr][nt];
+    int nt = pick_nt(a.Cout, tm, pr), ks = 1, ad = 2;
+    if (pr == PREC_F32) return names[pr][nt];
+    conv2d_split_plan(a, nt, &nt, &ks, &ad);
+    // the 256-row A-direct kernel keeps the plain name; the other structures and split-K runs are separate kinds, so that a
+    // kind's average launch time is one kernel's (bench.py roofline vs the rocprofv3 kernel trace)
+    static std::string pool[4][6][3][2];
+    std::string& n = pool[pr][nt][ad][ks > 1];
+    if (n.empty()) n = std::string(names[pr][nt]) + (ad == 2 ? "" : (ad == 1 ? "/r128" : "/staged")) + (ks > 1 ? "+splitk" : "");
+    return n.c_str();
 }
 
 void conv2d(ConvArgs a, hipStream_t s) {
