@@ -15,7 +15,8 @@
 // per CU 221-229 / 378-384 (the default on the large layers).  Measured and removed: producer/consumer wave specialisation
 // 165 / 326; a schedule pinned group by group without the pipelining 196; the 256-row kernel on the 16x16x32 MFMA shape
 // 223 / 355 (no clock gain here, MI355X_MICROARCH.md "DVFS give-back" 7 notwithstanding); a third weight stage that moves
-// the first fragment read of a tile in front of the barrier 220 / 355.
+// the first fragment read of a tile in front of the barrier 220 / 355; a 128 x 320 tile (one activation load and split
+// per k-tile for the whole output width, twice the LDS reads per MFMA) 210 / 368.
 // PMC (profiles/r01_pmc.json): MFMA pipe busy 71 %, clock 1.80 GHz, no LDS bank conflicts; 6 x 226 = 1.36 PF/s issued =
 // 54 % of the nominal bf16 peak, 72 % of what the matrix pipes deliver at the clock the chip holds under this load.
 //
