@@ -432,6 +432,78 @@ __global__ __launch_bounds__(256) void conv_direct_lds_kernel(ConvP p) {
     }
 }
 
+// First layer (Cin = 1, K = 9 -> 320 channels at 256x256): pure output-write traffic.  A thread owns four fixed output
+// channels, keeps their K x 4 weights and bias in registers and walks over pixels: per pixel K broadcast loads, 4K FMAs and
+// one 16-byte store, no LDS and no per-element index divisions (the LDS version above reaches 1.9 TB/s, this one the
+// store rate of the elementwise kernels).
+template <int KMAX>
+__global__ __launch_bounds__(256) void conv_direct_cols_kernel(ConvP p, int W4, int ppb) {
+    const int c4n = p.Cout >> 2;
+    const int rpi = blockDim.x / W4;
+    const int row = threadIdx.x / W4;
+    const int c4 = threadIdx.x - row * W4;
+    if (c4 >= c4n) return;
+    float4 w[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        if (k < p.Ktot) {
+            w[k].x = p.w[(int64_t)(c4 * 4 + 0) * p.Ktot + k];
+            w[k].y = p.w[(int64_t)(c4 * 4 + 1) * p.Ktot + k];
+            w[k].z = p.w[(int64_t)(c4 * 4 + 2) * p.Ktot + k];
+            w[k].w = p.w[(int64_t)(c4 * 4 + 3) * p.Ktot + k];
+        } else {
+            w[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    int dh[KMAX], dw[KMAX], dc[KMAX];   // filter-tap offsets of k, once per thread (no divisions in the pixel loop)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int tap = k / p.Cin;
+        dc[k] = k - tap * p.Cin;
+        dh[k] = tap / p.ks - p.pad;
+        dw[k] = tap - (tap / p.ks) * p.ks - p.pad;
+    }
+    const float4 b4 = p.bias ? *reinterpret_cast<const float4*>(p.bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t m_end = min((int64_t)p.M, ((int64_t)blockIdx.x + 1) * ppb);
+    int64_t m = (int64_t)blockIdx.x * ppb + row;
+    int nb = (int)(m / p.ohw);
+    int oh = (int)(m - (int64_t)nb * p.ohw) / p.OW;
+    int ow = (int)(m - (int64_t)nb * p.ohw) - oh * p.OW;
+    for (; m < m_end; m += rpi, ow += rpi) {
+        while (ow >= p.OW) {   // pixel coordinates advance incrementally: no division per pixel
+            ow -= p.OW;
+            if (++oh == p.OH) {
+                oh = 0;
+                ++nb;
+            }
+        }
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* xb = p.x + (int64_t)nb * p.x_bs;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            int ih = oh * p.stride + dh[k], iw = ow * p.stride + dw[k];
+            const bool ok = (k < p.Ktot) & ((unsigned)ih < (unsigned)p.IHg) & ((unsigned)iw < (unsigned)p.IWg);
+            ih >>= p.ups;
+            iw >>= p.ups;
+            const float xv = ok ? xb[((int64_t)ih * p.W + iw) * p.Cin + dc[k]] : 0.f;
+            acc.x = fmaf(xv, w[k].x, acc.x);
+            acc.y = fmaf(xv, w[k].y, acc.y);
+            acc.z = fmaf(xv, w[k].z, acc.z);
+            acc.w = fmaf(xv, w[k].w, acc.w);
+        }
+        acc.x += b4.x; acc.y += b4.y; acc.z += b4.z; acc.w += b4.w;   // bias after the fma chain, like every other epilogue
+        if (p.emb) {
+            const float4 e = *reinterpret_cast<const float4*>(p.emb + (int64_t)nb * p.emb_stride + c4 * 4);
+            acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
+        }
+        if (p.res) {
+            const float4 e = *reinterpret_cast<const float4*>(p.res + m * p.Cout + c4 * 4);
+            acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
+        }
+        *reinterpret_cast<float4*>(p.y + m * p.Cout + c4 * 4) = acc;
+    }
+}
+
 // Fully generic scalar fallback (odd channel counts; never on the hot configs).
 __global__ __launch_bounds__(256) void conv_scalar_kernel(ConvP p) {
     const int64_t total = (int64_t)p.M * p.Cout;
@@ -552,7 +624,10 @@ size_t conv2d_scratch_bytes(const ConvArgs& a) {
 
 const char* conv2d_variant(const ConvArgs& a) {
     const int Ktot = a.ks * a.ks * a.Cin;
-    if (a.Cin % 4 != 0 || Ktot < 32) return (a.Cout % 4 == 0 && (size_t)Ktot * a.Cout * 4 <= 60 * 1024) ? "conv_direct_lds" : "conv_scalar";
+    if (a.Cin % 4 != 0 || Ktot < 32) {
+        if (a.Cout % 4 == 0 && a.Cout / 4 <= 256 && Ktot <= 9 && !a.out_nchw && (!a.emb || a.emb_stride % 4 == 0)) return "conv_direct_cols";
+        return (a.Cout % 4 == 0 && (size_t)Ktot * a.Cout * 4 <= 60 * 1024) ? "conv_direct_lds" : "conv_scalar";
+    }
     const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
     const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
     static const char* names[4][6] = {{"", "conv_mfma<1>", "conv_mfma<2>", "conv_mfma<3>", "conv_mfma<4>", "conv_mfma<5>"},
@@ -595,7 +670,12 @@ void conv2d(ConvArgs a, hipStream_t s) {
 
     if (a.Cin % 4 != 0 || p.Ktot < 32) {
         const size_t lds = (size_t)p.Ktot * a.Cout * sizeof(float);
-        if (a.Cout % 4 == 0 && lds <= 60 * 1024) {
+        if (a.Cout % 4 == 0 && a.Cout / 4 <= 256 && p.Ktot <= 9 && !a.out_nchw && (!a.emb || a.emb_stride % 4 == 0)) {
+            const int W4 = a.Cout / 4, rpi = 256 / W4;
+            const int ppb = std::max(rpi * 8, cdiv(cdiv(p.M, 8192), rpi) * rpi);
+            hipLaunchKernelGGL(conv_direct_cols_kernel<9>, dim3(cdiv(p.M, ppb)), dim3(rpi * W4), 0, s, p, W4, ppb);
+            check_launch("conv_direct_cols");
+        } else if (a.Cout % 4 == 0 && lds <= 60 * 1024) {
             hipLaunchKernelGGL(conv_direct_lds_kernel, dim3(cdiv(p.M, 64)), dim3(256), lds, s, p);
             check_launch("conv_direct_lds");
         } else {
