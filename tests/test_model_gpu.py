@@ -208,6 +208,10 @@ def full_model():
 
 def test_full_config_forward_vs_oracle(full_model):
     m, cfg, sd = full_model
+    # raw BraTS slices are 240x240; the reference's skip concat fails on them and so must the drop-in
+    from diffusion_models_dsdiff_amd import _lib
+    with pytest.raises((_lib.DsdError, AssertionError, RuntimeError)):
+        m(torch.zeros(1, 2, 240, 240).cuda(), torch.tensor([5]).cuda())
     for C, seed in ((2, 5), (4, 6)):
         x = randn((1, C, 64, 64), seed)
         t = torch.tensor([731])
