@@ -47,6 +47,7 @@ struct ConvP {
     int N, H, W, Cin, Cout, OH, OW, ks, stride, pad, ups, emb_stride, out_nchw;
     int M, Ktot, cchunks, IHg, IWg, tiles_m, tiles_n, ohw;
     unsigned x_bytes, w_bytes;  // buffer-descriptor extents (buffer-load kernel only)
+    int y_ld;                   // row stride of y (>= Cout)
 };
 
 
@@ -84,7 +85,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x16 (&acc
             }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                float* yp = p.y + (int64_t)(mb + rr) * p.Cout + n0 + lrow;
+                float* yp = p.y + (int64_t)(mb + rr) * p.y_ld + n0 + lrow;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     float v = acc[j][4 * g + rr] + bj[j];
@@ -114,7 +115,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvP& p, const f32x16 (&acc
                 const int pix = m - nb * p.ohw;
                 p.y[((int64_t)nb * p.Cout + n) * p.ohw + pix] = v;
             } else {
-                p.y[(int64_t)m * p.Cout + n] = v;
+                p.y[(int64_t)m * p.y_ld + n] = v;
             }
         }
     }
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) void conv_direct_lds_kernel(ConvP p) {
         if (p.out_nchw) {
             for (int q = 0; q < 4; ++q) p.y[((int64_t)nb * p.Cout + c4 * 4 + q) * p.ohw + r] = v[q];
         } else {
-            *reinterpret_cast<float4*>(p.y + m * p.Cout + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(p.y + m * p.y_ld + c4 * 4) = make_float4(v[0], v[1], v[2], v[3]);
         }
     }
 }
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(256) void conv_direct_cols_kernel(ConvP p, int W4, 
             const float4 e = *reinterpret_cast<const float4*>(p.res + m * p.Cout + c4 * 4);
             acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
         }
-        *reinterpret_cast<float4*>(p.y + m * p.Cout + c4 * 4) = acc;
+        *reinterpret_cast<float4*>(p.y + m * p.y_ld + c4 * 4) = acc;
     }
 }
 
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(256) void conv_scalar_kernel(ConvP p) {
         if (p.out_nchw)
             p.y[((int64_t)nb * p.Cout + n) * p.ohw + r] = acc;
         else
-            p.y[m * p.Cout + n] = acc;
+            p.y[m * p.y_ld + n] = acc;
     }
 }
 
@@ -653,6 +654,7 @@ void conv2d(ConvArgs a, hipStream_t s) {
     ConvP p{};
     p.x = a.x; p.w = a.w; p.bias = a.bias; p.emb = a.emb; p.res = a.res; p.y = a.y;
     p.N = a.N; p.H = a.H; p.W = a.W; p.Cin = a.Cin; p.Cout = a.Cout; p.ks = a.ks; p.stride = a.stride;
+    p.y_ld = a.y_ld > 0 ? a.y_ld : a.Cout;
     p.pad = a.ks / 2; p.ups = a.ups; p.emb_stride = a.emb_stride; p.out_nchw = a.out_nchw;
     p.x_bs = a.x_bs >= 0 ? a.x_bs : (int64_t)a.H * a.W * a.Cin;
     p.IHg = a.ups ? a.H * 2 : a.H;

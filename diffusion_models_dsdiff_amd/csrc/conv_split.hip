@@ -55,6 +55,7 @@ struct SplitP {
     int M, Ktot, cchunks, IHg, IWg, tiles_m, tiles_n, ohw;
     unsigned x_bytes, w_bytes, w_plane_bytes;
     int* ovf;   // f16x3 only: set to 1 when an operand magnitude exceeds the fp16 range (caller reports it)
+    int y_ld;         // row stride of y (>= Cout)
     int ksplit;       // split-K: the k-tiles are divided over ksplit workgroups per output tile (A-direct 128-row kernel)
     float* partial;   // [ksplit][M][Cout] raw partial sums, reduced (+ bias / embedding / residual) by splitk_reduce_kernel
 };
@@ -143,7 +144,7 @@ __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&a
             }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                float* yp = p.y + (int64_t)(mb + rr) * p.Cout + n0 + lrow;
+                float* yp = p.y + (int64_t)(mb + rr) * p.y_ld + n0 + lrow;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     float v = acc[j][4 * g + rr] + bj[j];
@@ -171,7 +172,7 @@ __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&a
             if (p.out_nchw)
                 p.y[((int64_t)nb * p.Cout + n) * p.ohw + (m - nb * p.ohw)] = v;
             else
-                p.y[(int64_t)m * p.Cout + n] = v;
+                p.y[(int64_t)m * p.y_ld + n] = v;
         }
     }
 }
@@ -625,6 +626,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         q.y = p.partial + (int64_t)chunk * p.M * p.Cout;
         q.bias = q.emb = q.res = nullptr;
         q.out_nchw = 0;
+        q.y_ld = p.Cout;
 #pragma unroll
         for (int r = 0; r < RB; ++r) split_epilogue<NT>(q, acc[r], m0, n0, wave * RB + r, lrow, half, SBM * RB);
         return;
@@ -637,7 +639,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int S, int M, int Cout,
                                                             const float* __restrict__ bias, const float* __restrict__ emb,
                                                             int emb_stride, int ohw, const float* __restrict__ res,
-                                                            float* __restrict__ y, int out_nchw) {
+                                                            float* __restrict__ y, int y_ld, int out_nchw) {
     const int64_t total4 = (int64_t)M * Cout / 4;
     const int64_t plane = (int64_t)M * Cout;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
@@ -654,7 +656,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 #pragma unroll
             for (int k = 0; k < 4; ++k) y[((int64_t)nb * Cout + n + k) * ohw + r] = v[k];
         } else {
-            *reinterpret_cast<f32x4*>(y + e) = v;
+            *reinterpret_cast<f32x4*>(y + (int64_t)m * y_ld + n) = v;
         }
     }
 }
@@ -799,6 +801,7 @@ void conv2d_split(const ConvArgs& a, int nt, int ksplit, int ad, hipStream_t s) 
     p.x = a.x; p.w = a.w_split; p.bias = a.bias; p.emb = a.emb; p.res = a.res; p.y = a.y;
     p.N = a.N; p.H = a.H; p.W = a.W; p.Cin = a.Cin; p.Cout = a.Cout; p.ks = a.ks; p.stride = a.stride;
     p.pad = a.ks / 2; p.ups = a.ups; p.emb_stride = a.emb_stride; p.out_nchw = a.out_nchw;
+    p.y_ld = a.y_ld > 0 ? a.y_ld : a.Cout;
     p.x_bs = a.x_bs >= 0 ? a.x_bs : (int64_t)a.H * a.W * a.Cin;
     p.IHg = a.ups ? a.H * 2 : a.H;
     p.IWg = a.ups ? a.W * 2 : a.W;
@@ -838,7 +841,7 @@ void conv2d_split(const ConvArgs& a, int nt, int ksplit, int ad, hipStream_t s) 
     if (p.ksplit > 1) {
         const int64_t total4 = (int64_t)p.M * a.Cout / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)std::min<int64_t>((total4 + 255) / 256, 2048)), dim3(256), 0, s,
-                           p.partial, p.ksplit, p.M, a.Cout, a.bias, a.emb, a.emb_stride, p.ohw, a.res, a.y, a.out_nchw);
+                           p.partial, p.ksplit, p.M, a.Cout, a.bias, a.emb, a.emb_stride, p.ohw, a.res, a.y, p.y_ld, a.out_nchw);
         check_launch("splitk_reduce");
     }
 }

@@ -18,6 +18,8 @@ struct ConvArgs {
     int emb_stride = 0;
     const float* res = nullptr; // residual NHWC [N,OH,OW,Cout] added in the epilogue (skip_connection(x) + h)
     float* y = nullptr;
+    int y_ld = 0;               // row stride of y in elements (0 -> Cout): lets a conv write a channel slice of a wider
+                                // NHWC tensor, e.g. the decoder's concat buffer (torch.cat([h, skip]) never copied)
     int out_nchw = 0;           // store as [N,Cout,OH,OW] (final layer with out_channels > 1)
     int OH = 0, OW = 0;         // filled by conv2d()
     int variant = -1;           // kernel variant override (-1 = default / env DSD_CONV_VARIANT)

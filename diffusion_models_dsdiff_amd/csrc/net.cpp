@@ -449,8 +449,11 @@ struct Builder {
     bool has(const std::string& n) { return hd->pidx.count(n) != 0; }
 
     // ---- convolution: src is an arena tensor, or (plane >= 0) one of the caller's input planes
+    // dst != nullptr: the result is written into channels [0, cout) of the wider NHWC tensor *dst (row stride dst->c) instead
+    // of a tensor of its own — the decoder's cat([h, skip]) without the copy of h; the returned Tn is then a view of *dst.
     Tn conv(const std::string& name, const Tn& x, int cout, int ks, int stride = 1, bool ups = false,
-            const EmbRef* emb = nullptr, const Tn* res = nullptr, int plane = -1, bool to_out = false, bool bias = true) {
+            const EmbRef* emb = nullptr, const Tn* res = nullptr, int plane = -1, bool to_out = false, bool bias = true,
+            const Tn* dst = nullptr) {
         ConvArgs a;
         a.N = x.n; a.H = x.h; a.W = x.w; a.Cin = x.c; a.Cout = cout; a.ks = ks; a.stride = stride; a.ups = ups ? 1 : 0;
         a.w = W(name + ".weight");
@@ -461,7 +464,15 @@ struct Builder {
         const int IHg = ups ? x.h * 2 : x.h, IWg = ups ? x.w * 2 : x.w, pad = ks / 2;
         const int OH = (IHg + 2 * pad - ks) / stride + 1, OW = (IWg + 2 * pad - ks) / stride + 1;
         Tn y;
-        if (!to_out) y = alloc(x.n, OH, OW, cout);
+        if (dst) {
+            DSD_CHECK(!to_out && dst->n == x.n && dst->h == OH && dst->w == OW && dst->c >= cout && dst->c % 4 == 0,
+                      "conv %s: destination view does not fit", name.c_str());
+            y = *dst;
+            y.c = cout;
+        } else if (!to_out) {
+            y = alloc(x.n, OH, OW, cout);
+        }
+        const int y_ld = dst ? dst->c : 0;
         if (res) DSD_CHECK(res->n == x.n && res->h == OH && res->w == OW && res->c == cout, "conv %s: residual shape mismatch", name.c_str());
         if (hd->precision != PREC_F32 && x.c % 32 == 0 && plane < 0) {   // split-bf16 arithmetic: pieces of the (packed) weight
             const bool f16 = hd->precision == PREC_F16X3;
@@ -501,6 +512,7 @@ struct Builder {
                 c.x_bs = -1;
             }
             c.y = to_out ? h->io.out : reinterpret_cast<float*>(h->arena + yoff);
+            c.y_ld = y_ld;
             c.out_nchw = nchw ? 1 : 0;
             if (e.valid) {
                 c.emb = reinterpret_cast<const float*>(h->arena + e.arena_off) + e.col;
@@ -567,7 +579,8 @@ struct Builder {
     }
 
     // ResBlock._forward, openaimodel.py:264-284.  x stays owned by the caller.
-    Tn res_block(const std::string& p, const Tn& x, int cin, int cout, bool up, bool down, const EmbRef& emb) {
+    Tn res_block(const std::string& p, const Tn& x, int cin, int cout, bool up, bool down, const EmbRef& emb,
+                 const Tn* dst = nullptr) {
         DSD_CHECK(x.c == cin, "ResBlock %s: input has %d channels, expected %d", p.c_str(), x.c, cin);
         const bool film = hd->PP(pre(p, "emb_layers.1.weight")).shape[0] == 2 * cout;
         Tn a = gn_act(pre(p, "in_layers.0"), x, ACT_SILU);
@@ -590,7 +603,7 @@ struct Builder {
             skip = conv(pre(p, "skip_connection"), xs, cout, 1);
             skip_owned = true;
         }
-        Tn out = conv(pre(p, "out_layers.3"), a3, cout, 3, 1, false, nullptr, &skip);
+        Tn out = conv(pre(p, "out_layers.3"), a3, cout, 3, 1, false, nullptr, &skip, -1, false, true, dst);
         release(a3);
         if (skip_owned) release(skip);
         if (xs_owned) release(xs);
@@ -598,7 +611,7 @@ struct Builder {
     }
 
     // AttentionBlock._forward, openaimodel.py:467-473
-    Tn attn_block(const std::string& p, const Tn& x, int heads, bool new_order) {
+    Tn attn_block(const std::string& p, const Tn& x, int heads, bool new_order, const Tn* dst = nullptr) {
         const int C = x.c, T = x.hw();
         DSD_CHECK(C % heads == 0, "attention %s: %d channels not divisible by %d heads", p.c_str(), C, heads);
         const int d = C / heads;
@@ -632,7 +645,7 @@ struct Builder {
             }, 1, "attention", 4.0 * x.n * heads * (double)T * T * d);
         }
         release(qkv);
-        Tn out = conv(pre(p, "proj_out"), a, C, 1, 1, false, nullptr, &x);
+        Tn out = conv(pre(p, "proj_out"), a, C, 1, 1, false, nullptr, &x, -1, false, true, dst);
         release(a);
         return out;
     }
@@ -689,19 +702,20 @@ struct Builder {
 
     // TimestepEmbedSequential.forward, openaimodel.py:80-90.  Consumes (releases) x unless keep_input.
     Tn block(const std::string& prefix, const std::vector<Layer>& layers, Tn x, bool keep_input,
-             const std::vector<EmbRef>& embs, size_t& emb_i, int plane = -1) {
+             const std::vector<EmbRef>& embs, size_t& emb_i, int plane = -1, const Tn* dst = nullptr) {
         Tn cur = x;
         bool cur_owned = !keep_input;
         for (size_t li = 0; li < layers.size(); ++li) {
             const Layer& L = layers[li];
             const std::string nm = prefix + "." + std::to_string(li);
             Tn nxt;
+            const Tn* d = li + 1 == layers.size() ? dst : nullptr;   // only the block's last layer writes into the view
             switch (L.kind) {
-                case L_CONV: nxt = conv(nm, cur, L.cout, 3, 1, false, nullptr, nullptr, plane); break;
-                case L_RES: nxt = res_block(nm, cur, L.cin, L.cout, L.up, L.down, embs.at(emb_i++)); break;
-                case L_ATTN: nxt = attn_block(nm, cur, L.heads, hd->cfg.use_new_attention_order != 0); break;
-                case L_DOWN: nxt = conv(nm + ".op", cur, L.ch, 3, 2); break;
-                case L_UP: nxt = conv(nm + ".conv", cur, L.ch, 3, 1, true); break;
+                case L_CONV: nxt = conv(nm, cur, L.cout, 3, 1, false, nullptr, nullptr, plane, false, true, d); break;
+                case L_RES: nxt = res_block(nm, cur, L.cin, L.cout, L.up, L.down, embs.at(emb_i++), d); break;
+                case L_ATTN: nxt = attn_block(nm, cur, L.heads, hd->cfg.use_new_attention_order != 0, d); break;
+                case L_DOWN: nxt = conv(nm + ".op", cur, L.ch, 3, 2, false, nullptr, nullptr, -1, false, true, d); break;
+                case L_UP: nxt = conv(nm + ".conv", cur, L.ch, 3, 1, true, nullptr, nullptr, -1, false, true, d); break;
             }
             if (cur_owned && plane < 0) release(cur);
             plane = -1;
@@ -965,20 +979,40 @@ void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats, bool 
     b.release(cat);
     // ---- decoder (model.py:743-746): cat[h, (hs+hs_a+hs_al+hs_l)/4]
     auto dembs = embs_for("output_blocks", sp.output_blocks);
+    // The concat buffer of block bi+1 is allocated before block bi runs, and block bi's last convolution writes h straight
+    // into its first channels (row stride = concat width): torch.cat([h, skip]) costs no copy of h.
+    auto block_out = [&](const std::vector<Layer>& layers, int c, int hh, int ww, int* oc, int* oh, int* ow) {
+        *oc = c; *oh = hh; *ow = ww;
+        for (const Layer& L : layers) {
+            if (L.kind == L_RES || L.kind == L_CONV) *oc = L.cout;
+            if (L.kind == L_UP || (L.kind == L_RES && L.up)) { *oh *= 2; *ow *= 2; }
+            if (L.kind == L_DOWN || (L.kind == L_RES && L.down)) { *oh /= 2; *ow /= 2; }
+        }
+    };
+    Tn c2 = b.alloc(B, h.h, h.w, h.c + hs[0].back().c);
+    b.avg(&h, 1, 1.f, c2, 0, ACT_NONE);
+    b.release(h);
     for (size_t bi = 0; bi < sp.output_blocks.size(); ++bi) {
         Tn sk[4];
         for (int s = 0; s < 4; ++s) {
             sk[s] = hs[s].back();
             hs[s].pop_back();
         }
-        Tn c2 = b.alloc(B, h.h, h.w, h.c + sk[0].c);
-        DSD_CHECK(sk[0].h == h.h && sk[0].w == h.w, "decoder skip shape mismatch at output_blocks.%zu", bi);
-        b.avg(&h, 1, 1.f, c2, 0, ACT_NONE);
-        b.avg(sk, 4, 4.f, c2, h.c, ACT_NONE);
-        b.release(h);
+        DSD_CHECK(sk[0].h == c2.h && sk[0].w == c2.w, "decoder skip shape mismatch at output_blocks.%zu", bi);
+        const int hc = c2.c - sk[0].c;
+        b.avg(sk, 4, 4.f, c2, hc, ACT_NONE);
         for (auto& t : sk) b.release(t);
+        const bool last = bi + 1 == sp.output_blocks.size();
+        Tn next;
+        if (!last) {
+            int oc, oh, ow;
+            block_out(sp.output_blocks[bi], c2.c, c2.h, c2.w, &oc, &oh, &ow);
+            next = b.alloc(B, oh, ow, oc + hs[0].back().c);
+        }
         size_t ei = 0;
-        h = b.block("output_blocks." + std::to_string(bi), sp.output_blocks[bi], c2, /*keep_input=*/false, dembs[bi], ei);
+        Tn out = b.block("output_blocks." + std::to_string(bi), sp.output_blocks[bi], c2, /*keep_input=*/false, dembs[bi], ei,
+                         -1, last ? nullptr : &next);
+        if (last) h = out; else c2 = next;
     }
     // ---- out = Conv3x3(SiLU(GN(h)))  (model.py:511-515,751)
     Tn a = b.gn_act("out.0", h, ACT_SILU);
