@@ -435,6 +435,23 @@ int dsd_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w_o
     DSD_CATCH
 }
 
+int dsd_conv_plan(int N, int H, int W, int Cin, int Cout, int ks, int stride, int precision, int* structure, int* nt,
+                  int* ksplit, uint64_t* scratch_bytes) {
+    DSD_TRY
+    DSD_CHECK(structure && nt && ksplit && scratch_bytes, "null argument");
+    ConvArgs a;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ks = ks; a.stride = stride;
+    a.precision = precision & 3;
+    if (precision & 16) a.variant = 30;
+    if (precision & 32) a.variant = 31;
+    if (precision & 64) a.variant = 32;
+    static const int dummy = 0;
+    a.w_split = a.precision != PREC_F32 ? &dummy : nullptr;   // only its presence matters to the eligibility test
+    conv2d_plan_query(a, structure, nt, ksplit);
+    *scratch_bytes = conv2d_scratch_bytes(a);
+    DSD_CATCH
+}
+
 int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride, int variant, int iters, float* avg_ms,
                      double* flops) {
     DSD_TRY

@@ -623,6 +623,18 @@ size_t conv2d_scratch_bytes(const ConvArgs& a) {
     return ks > 1 ? (size_t)ks * M * a.Cout * sizeof(float) : 0;
 }
 
+void conv2d_plan_query(const ConvArgs& a, int* structure, int* nt_out, int* ks_out) {
+    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
+    const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
+    const int tm = cdiv((int64_t)a.N * OH * OW, BM);
+    const int pr = effective_precision(a, tm);
+    int nt = pick_nt(a.Cout, tm, pr), ks = 1, ad = -1;
+    if (pr != PREC_F32) conv2d_split_plan(a, nt, &nt, &ks, &ad);
+    *structure = ad;
+    *nt_out = nt;
+    *ks_out = ks;
+}
+
 const char* conv2d_variant(const ConvArgs& a) {
     const int Ktot = a.ks * a.ks * a.Cin;
     if (a.Cin % 4 != 0 || Ktot < 32) {

@@ -40,7 +40,8 @@ size_t conv2d_scratch_bytes(const ConvArgs& a);   // workspace conv2d() can use 
 // N-tile width (in 32-column units) and split-K factor the split-precision path runs this problem with; nt_default is the
 // width the generic cost model (conv.hip pick_nt) would take
 void conv2d_split_plan(const ConvArgs& a, int nt_default, int* nt, int* ksplit, int* structure = nullptr, bool allow_split = true);
-const char* conv2d_variant(const ConvArgs& a);   // name of the kernel conv2d() will launch for these arguments
+const char* conv2d_variant(const ConvArgs& a);
+void conv2d_plan_query(const ConvArgs& a, int* structure, int* nt, int* ksplit);   // what conv2d() would launch   // name of the kernel conv2d() will launch for these arguments
 void pack_ohwi(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, hipStream_t s);
 
 // ---------------------------------------------------------------- norm.hip

@@ -233,9 +233,14 @@ int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float
 /* Micro-benchmark of the convolution kernel on random data (library-owned buffers): average ms per launch over
  * `iters` back-to-back launches (hipEvents) and the algorithmic FLOPs of one launch.  variant: -1/0 default fp32
  * kernel, 1 flat-load fp32 kernel, 10 bf16x3, 11 bf16x6, 12 f16x3 (library's choice of structure), 20/21 both operands staged
- * through LDS, 30/31 activations read straight into registers. */
+ * through LDS, 30/31 activations read straight into registers (128-row tile), 40/41/42 the same on the 256-row tile. */
 int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride, int variant, int iters, float* avg_ms,
                      double* flops);
+/* How the library would run a convolution (host-side query, no GPU work): kernel structure (0 both operands staged
+ * through LDS, 1 / 2 activations read straight into registers with a 128 / 256-row tile; -1 for the fp32 kernel), N-tile
+ * width in 32-column units, split-K factor and the scratch bytes the split needs.  precision as in dsd_op_conv2d_prec. */
+int dsd_conv_plan(int N, int H, int W, int Cin, int Cout, int ks, int stride, int precision, int* structure, int* nt,
+                  int* ksplit, uint64_t* scratch_bytes);
 /* GroupNorm(32, C, eps) [+ SiLU] on x[N,HW,C]. */
 int dsd_op_group_norm(const float* x, int N, int HW, int C, const float* gamma, const float* beta, float eps,
                       int silu, float* y, void* stream);

@@ -203,3 +203,39 @@ def test_dpm_unsupported_options_raise():
         sol.sample(x, steps=6)
     with pytest.raises(ValueError):
         dsa.NoiseScheduleVP("cosine")
+
+
+# ---------------------------------------------------------------------------------------- convolution planner (host)
+def _conv_plan(N, H, W, Cin, Cout, ks=3, stride=1, precision=2):
+    import ctypes as C
+    st, nt, ksp, sb = C.c_int(), C.c_int(), C.c_int(), C.c_uint64()
+    _lib.check(_lib.lib().dsd_conv_plan(N, H, W, Cin, Cout, ks, stride, precision, C.byref(st), C.byref(nt), C.byref(ksp), C.byref(sb)))
+    return st.value, nt.value, ksp.value, sb.value
+
+
+def test_conv_plan_invariants():
+    """dsd_conv_plan is pure host logic: structure / tile width / split-K of the layers of the BASELINE network.  The
+    headline layers must stay on the 256-row A-direct kernel with the widest tile and no split; small grids split their
+    k-loop, ask for exactly ksplit*M*Cout*4 scratch bytes and never more workgroups than the model allows; fp32 mode and
+    shapes the split kernels cannot take fall back."""
+    for shape in ((16, 256, 256, 320, 320), (16, 256, 256, 640, 320), (16, 128, 128, 320, 320), (16, 64, 64, 640, 640),
+                  (16, 32, 32, 640, 640)):
+        st, nt, ks, sb = _conv_plan(*shape)
+        assert (st, nt, ks, sb) == (2, 5, 1, 0), shape
+    for shape in ((16, 8, 8, 960, 960), (16, 8, 8, 1920, 960), (1, 8, 8, 960, 960), (1, 16, 16, 960, 960), (1, 32, 32, 640, 640)):
+        N, H, W, Cin, Cout = shape
+        st, nt, ks, sb = _conv_plan(*shape)
+        assert st in (1, 2) and 1 <= nt <= 5 and 2 <= ks <= 16, (shape, st, nt, ks)
+        assert sb == ks * N * H * W * Cout * 4, shape
+        assert (9 * Cin // 32) // ks >= 8, shape                       # every chunk keeps at least 8 k-tiles
+        rows = 128 * st
+        blocks = -(-N * H * W // rows) * -(-(Cout // 32) // nt) * ks
+        assert blocks <= 768, (shape, blocks)
+    assert _conv_plan(16, 8, 8, 960, 480, ks=1)[2] >= 1                 # K = 30 tiles: at most x3
+    assert _conv_plan(16, 256, 256, 320, 320, precision=0)[0] == -1     # fp32 mode: the fp32 kernel
+    assert _conv_plan(16, 256, 256, 1, 320)[0] == -1                    # C_in = 1: direct kernel, never split precision
+    assert _conv_plan(1, 16, 16, 320, 1)[2] == 1                        # C_out = 1 cannot use the float4 reduction
+    assert _conv_plan(16, 256, 256, 320, 320, precision=1)[0] == 2      # bf16x3: 256-row tile on the big layers
+    assert _conv_plan(16, 16, 16, 960, 960, precision=1)[0] == 0        # ... staged structure at M = 4096
+    assert _conv_plan(16, 256, 256, 320, 320, precision=2 | 16)[0] == 1 # forced structures are honoured
+    assert _conv_plan(16, 256, 256, 320, 320, precision=2 | 32)[0] == 0
