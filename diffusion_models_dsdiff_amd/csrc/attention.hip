@@ -55,21 +55,40 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const float* kbase = a.k + (int64_t)n * a.Tk * a.ldk + (int64_t)head * a.k_hs;
     const float* vbase = a.v + (int64_t)n * a.Tk * a.ldv + (int64_t)head * a.v_hs;
     constexpr int C4 = DP / 4;  // float4 columns per row
-    for (int k0 = 0; k0 < a.Tk; k0 += KEYS) {
-        __syncthreads();
-        for (int i = tid; i < KEYS * C4; i += 256) {
+    constexpr int NLD = KEYS * C4 / 256;   // float4 (K, V) pairs each thread stages per tile
+    static_assert(NLD * 256 == KEYS * C4, "the staging loop covers the tile exactly");
+    // The next K / V tile is fetched into registers while the current one is multiplied (the loads used to sit, fully
+    // exposed, between the two barriers of every tile).
+    float4 kreg[NLD], vreg[NLD];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * 256;
             const int kr = i / C4, c4 = i - kr * C4;
             const int key = k0 + kr, d = c4 * 4;
             float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
             if (key < a.Tk && d < a.d) {
                 kv = *reinterpret_cast<const float4*>(kbase + (int64_t)key * a.ldk + d);
                 vv = *reinterpret_cast<const float4*>(vbase + (int64_t)key * a.ldv + d);
-                kv.x *= a.scale_k; kv.y *= a.scale_k; kv.z *= a.scale_k; kv.w *= a.scale_k;
             }
+            kreg[j] = kv;
+            vreg[j] = vv;
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < a.Tk; k0 += KEYS) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * 256;
+            const int kr = i / C4, d = (i - kr * C4) * 4;
+            float4 kv = kreg[j];
+            kv.x *= a.scale_k; kv.y *= a.scale_k; kv.z *= a.scale_k; kv.w *= a.scale_k;
             *reinterpret_cast<float4*>(Ks + kr * LS + d) = kv;
-            *reinterpret_cast<float4*>(Vs + kr * LS + d) = vv;
+            *reinterpret_cast<float4*>(Vs + kr * LS + d) = vreg[j];
         }
         __syncthreads();
+        if (k0 + KEYS < a.Tk) fetch(k0 + KEYS);
 #pragma unroll
         for (int sub = 0; sub < KEYS / 32; ++sub) {
             if (k0 + sub * 32 >= a.Tk) break;
