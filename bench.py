@@ -2,6 +2,7 @@
 """bench.py — 256x256 cDDPM slices/sec (1000-step) on N MI355X, one process per GPU.
 
     python bench.py --gpus 1 --steps 4 --warmup 1
+    python bench.py --gpus 8 ...            # no WORLD_SIZE in the env: this process launches the 8 ranks itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -14,14 +15,24 @@ Philox noise.  Inputs are resident in HBM before the timed region.
 A "step" is ONE denoising step (network evaluation + fused sampler update) of that chain for the whole
 batch: K consecutive steps of the 1000 are timed through dsd_sample(first_step, n_steps) — every step of the
 chain runs the same kernels on the same shapes, so  slices/s = B_total / (1000 * t_step).
-Slices are independent chains: ranks shard the slice batch, the only collective is the one-off RCCL
-broadcast of the packed weights from rank 0 ("scaling": "weak", batch 16 per GPU).
+Slices are independent chains: ranks shard the slice batch, the only collectives are the one-off RCCL
+broadcast of the packed weights from rank 0 and the final gather of the samples ("scaling": "weak", batch 16
+per GPU); the reference analogue of the broadcast is Disc_diff/guided_diffusion/dist_util.py:54-83.
+
+Rehearsal hooks (never set by the driver): DSD_BENCH_BACKEND=gloo runs the ranks over gloo,
+DSD_BENCH_SINGLE_DEVICE=1 puts every rank on device 0, DSD_BENCH_STUB=1 replaces the compute leg by a CPU stub so
+that launcher + rendezvous + barrier + max-over-ranks + gather can be tested without a GPU
+(tests/test_parallel_cpu.py); a stubbed line says so in `data` and carries no metric.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
 import time
 
@@ -31,10 +42,74 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32-in matrix peak
+PEAK_16BIT_MFMA_TFLOPS = 2500.0  # dense bf16 / fp16 MFMA peak (no sparsity)
 PEAK_HBM_GBS = 8000.0
 F_LIVE_PER_SLICE_STEP = 5.5427e12   # algorithmic FLOPs per 256^2 slice per step (dead heads dropped)
+HEADLINE = {"batch": 16, "size": 256, "model_channels": None}
+# MFMA products issued per fp32 multiply-add of the convolution, and the matrix peak of the dtype they are issued in
+PASSES = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "f16x3": 3}
+ISSUED_DTYPE = {"f32": "f32", "bf16x6": "bf16", "bf16x3": "bf16", "f16x3": "f16"}
 
 
+def issued_peak(precision):
+    return PEAK_FP32_MFMA_TFLOPS if precision == "f32" else PEAK_16BIT_MFMA_TFLOPS
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="slices per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "v2-1-cddpm-ds-disc.yaml"))
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel hipEvent pass")
+    ap.add_argument("--model-channels", type=int, default=None, help="override (debug only; invalidates the metric)")
+    ap.add_argument("--precision", default=os.environ.get("DSD_PRECISION", "bf16x6"), choices=list(PASSES),
+                    help="arithmetic of the convolutions (include/dsdiff.h: dsd_set_precision); default = library default")
+    ap.add_argument("--no-modes", action="store_true", help="do not also time the other arithmetic modes")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel from the host instead of replaying the "
+                                                            "captured hipGraph of a step")
+    return ap.parse_args(argv)
+
+
+# ======================================================================================== launcher (parent process)
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks (one per GPU) through
+    torch.distributed.run, relay rank 0's JSON line, exit with the worst child code.  This process never touches HIP
+    (no torch.cuda call before or after), so the children own the devices."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["DSD_BENCH_LAUNCHED_BY_PARENT"] = "1"
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in p.stdout:                      # stderr passes straight through
+        s = ln.strip()
+        if s.startswith("{") and '"metric"' in s:
+            line = s
+        else:
+            sys.stderr.write(ln)
+    rc = p.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+    return rc
+
+
+# ======================================================================================== compute legs
 def synth_weights_(model, seed):
     """torch.manual_seed(seed) default init (done by the ctor) + N(0, 0.02) for every all-zero parameter, in
     module-tree order."""
@@ -47,8 +122,10 @@ def synth_weights_(model, seed):
 
 def cpu_baseline(unet_params, sd, H, W, budget_s):
     """The oracle (CPU restatement pinned against the reference) timed on this host's cores: B=1 forwards of the
-    same network at the same resolution, as many as fit in ~budget_s (at least 1)."""
+    same network at the same resolution on a FIXED seeded input, as many as fit in ~budget_s (at least 1).  The
+    output of that forward is kept: the caller runs the same input through the GPU path (rel_l2_vs_cpu)."""
     from oracle import unet as O
+    from oracle.synth import randn
     cfg = O.UNetConfig.from_params(unet_params)
     # the GPU box reports every host core but a 1-GPU job owns a share of them: use the affinity mask, at most 32 threads
     try:
@@ -56,45 +133,229 @@ def cpu_baseline(unet_params, sd, H, W, budget_s):
     except AttributeError:
         n = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(n)
-    x = torch.randn(1, 2, H, W)
+    x = randn((1, 2, H, W), 7)
     t = torch.tensor([500])
-    times = []
+    times, y = [], None
     t_start = time.time()
     while True:
         t0 = time.time()
-        O.unet_forward(cfg, sd, x, t)
+        y = O.unet_forward(cfg, sd, x, t)[0]
         times.append(time.time() - t0)
         if time.time() - t_start + times[-1] > budget_s or len(times) >= 5:
             break
     step = sorted(times)[len(times) // 2]
-    return {"value": 1.0 / (1000.0 * step), "unit": "slices/s", "cores": n, "kind": "port",
-            "sample": f"{len(times)} forward(s) of the same U-Net at {H}x{W}, batch 1, fp32, torch-CPU oracle, "
-                      f"median {step:.2f} s/step, extrapolated x1000 steps"}
+    rep = {"value": 1.0 / (1000.0 * step), "unit": "slices/s", "cores": n, "kind": "port",
+           "sample": f"{len(times)} forward(s) of the same U-Net at {H}x{W}, batch 1, fp32, torch-CPU oracle, "
+                     f"median {step:.2f} s/step, extrapolated x1000 steps"}
+    return rep, x, t, y
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="slices per GPU")
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--config", default=os.path.join(ROOT, "configs", "v2-1-cddpm-ds-disc.yaml"))
-    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel hipEvent pass")
-    ap.add_argument("--model-channels", type=int, default=None, help="override (debug only; invalidates the metric)")
-    ap.add_argument("--precision", default=os.environ.get("DSD_PRECISION", "bf16x6"), choices=["f32", "bf16x6", "bf16x3", "f16x3"],
-                    help="arithmetic of the convolutions (include/dsdiff.h: dsd_set_precision); default = library default")
-    ap.add_argument("--no-modes", action="store_true", help="do not also time the other arithmetic modes")
-    args = ap.parse_args()
+def latest_pmc():
+    """Newest committed PMC summary (profiles/rNN_pmc.json, tools/profile_round.sh) and its provenance block."""
+    best, bn = None, -1
+    for p in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")):
+        m = re.match(r"r(\d+)_pmc\.json$", os.path.basename(p))
+        if m and int(m.group(1)) > bn:
+            best, bn = p, int(m.group(1))
+    return best
 
+
+class StubLeg:
+    """CPU stand-in for the compute leg (DSD_BENCH_STUB=1): exercises everything in this file that is not the GPU."""
+    stub = True
+
+    def __init__(self, args, rank, local, world):
+        self.args, self.rank, self.world = args, rank, world
+        self.dev = torch.device("cpu")
+        self.x = torch.full((args.batch, 1, 8, 8), float(rank))
+        self.gpu_name, self.n_cu, self.n_params, self.t_setup, self.bcast_ms = "stub", 0, 0, 0.0, None
+        if world > 1:
+            import torch.distributed as dist
+            flat = torch.full((1024,), float(rank))
+            t0 = time.time()
+            dist.broadcast(flat, 0)
+            self.bcast_ms = (time.time() - t0) * 1e3
+            assert float(flat[0]) == 0.0
+
+    def sync(self):
+        pass
+
+    def measure(self, precision, steps, warmup, profile_steps, barrier, reduce_max):
+        barrier()
+        t1 = time.time()
+        for _ in range(steps):
+            time.sleep(0.002 * (1 + self.rank))
+        barrier()
+        dt = time.time() - t1
+        ms, per_rank = reduce_max(dt / steps * 1e3)
+        return {"precision": precision, "ms_per_step": round(ms, 3), "per_rank_ms_per_step": per_rank,
+                "value": round((self.args.batch * self.world) / (1000.0 * ms / 1e3), 6), "whole_step_tflops": 0.0,
+                "finite": True, "info": {"workspace_bytes": 0, "launches": 0, "flops": 0.0}, "roofline": None,
+                "kernels": None}
+
+
+class GpuLeg:
+    stub = False
+
+    def __init__(self, args, rank, local, world):
+        import yaml
+        from diffusion_models_dsdiff_amd import _lib
+        from diffusion_models_dsdiff_amd.ldm.util import instantiate_from_config
+        from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
+        self.args, self.rank, self.world = args, rank, world
+        torch.cuda.set_device(local)
+        self.dev = dev = torch.device("cuda", local)
+        self.gpu_name, self.n_cu, _ = _lib.require_gpu(local)
+        cfg = yaml.safe_load(open(args.config))
+        self.mp = mp = cfg["model"]["params"]
+        uc = dict(mp["unet_config"])
+        uc["params"] = dict(uc["params"], device_index=local)
+        if args.model_channels:
+            uc["params"]["model_channels"] = args.model_channels
+        self.unet_params = uc["params"]
+        torch.manual_seed(2024)
+        t0 = time.time()
+        self.model = model = instantiate_from_config(uc)
+        model.set_precision(args.precision)
+        model.use_graph(not args.no_graph)
+        synth_weights_(model, 2024)
+        self.n_params = sum(p.numel() for p in model.parameters())
+        # one-off weight distribution: rank 0's parameters broadcast as ONE packed blob over RCCL/xGMI
+        self.bcast_ms = None
+        if world > 1:
+            import torch.distributed as dist
+            flat = torch.cat([p.data.reshape(-1) for p in model.parameters()]).to(dev)
+            torch.cuda.synchronize()
+            tb = time.time()
+            dist.broadcast(flat, 0)
+            torch.cuda.synchronize()
+            self.bcast_ms = (time.time() - tb) * 1e3
+            off = 0
+            for p in model.parameters():
+                p.data = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        model.sync_params(force=True)
+        self.t_setup = time.time() - t0
+        B, H, W = args.batch, args.size, args.size
+        diffusion = create_gaussian_diffusion(steps=mp.get("diffusion_steps", 1000), learn_sigma=mp.get("learn_sigma", False),
+                                              noise_schedule=mp.get("noise_schedule", "linear"),
+                                              predict_xstart=mp.get("predict_xstart", False),
+                                              rescale_timesteps=mp.get("rescale_timesteps", False),
+                                              timestep_respacing=mp.get("timestep_respacing", ""),
+                                              parameterization=mp.get("parameterization", "eps"))
+        self.sched = diffusion._schedule(False, 0.0, bool(mp.get("clip_denoised", True)))
+        assert self.sched.steps == 1000
+        self.g = g = torch.Generator(device=dev).manual_seed(2025 + rank)
+        self.cond = torch.randn(B, 1, H, W, device=dev, generator=g).clamp_(-1, 1)
+        self.x = torch.randn(B, 1, H, W, device=dev, generator=g)
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def measure(self, precision, steps, warmup, profile_steps, barrier, reduce_max):
+        """K timed denoising steps in one arithmetic mode (+ optional per-kernel hipEvent pass on rank 0)."""
+        from diffusion_models_dsdiff_amd import _lib
+        from diffusion_models_dsdiff_amd._sched import run_device_loop
+        model, sched, cond = self.model, self.sched, self.cond
+        B, H, W = self.args.batch, self.args.size, self.args.size
+        model.set_precision(precision)
+        if warmup > 0:
+            self.x = run_device_loop(model, sched, self.x, cond, seed=1234, first_step=0, n_steps=warmup)
+        else:
+            _lib.check(_lib.lib().dsd_plan(model._h, B, 2, H, W))
+        barrier()
+        t1 = time.time()
+        self.x = run_device_loop(model, sched, self.x, cond, seed=1234, first_step=warmup, n_steps=steps)
+        barrier()
+        dt = time.time() - t1
+        ms, per_rank = reduce_max(dt / steps * 1e3)
+        info = model.plan_info()
+        res = {"precision": precision, "ms_per_step": round(ms, 3), "per_rank_ms_per_step": per_rank,
+               "value": round((B * self.world) / (1000.0 * ms / 1e3), 6),
+               "whole_step_tflops": round(info["flops"] / (ms / 1e3) / 1e12, 2), "finite": bool(torch.isfinite(self.x).all()),
+               "info": info, "roofline": None, "kernels": None}
+        if profile_steps > 0 and self.rank == 0:
+            res["roofline"], res["kernels"] = self.profile(precision, warmup + steps, profile_steps, res)
+        return res
+
+    def profile(self, precision, first_step, profile_steps, res):
+        """Per-kernel durations measured live with hipEvents on the launch stream (dsd_profile_*; the captured graph is
+        bypassed while profiling), and the roofline block of the dominant kernel."""
+        from diffusion_models_dsdiff_amd._sched import run_device_loop
+        model = self.model
+        model.profile(True)
+        run_device_loop(model, self.sched, self.x, self.cond, seed=1234, first_step=first_step, n_steps=profile_steps)
+        rep, runs = model.profile_report()
+        model.profile(False)
+        tot_ms = sum(v["ms"] for v in rep.values())
+        dk, dv = max(rep.items(), key=lambda kv: kv[1]["ms"])
+        calls = max(dv["calls"], 1)
+        alg = dv["flops"] / (dv["ms"] / 1e3) / 1e12          # algorithmic (fp32-equivalent 2*MAC) TFLOP/s of its launches
+        passes = PASSES[precision]
+        peak = issued_peak(precision)
+        # HBM bytes per launch from the newest committed PMC passes of this same command (tools/profile_round.sh; separate
+        # --pmc runs, FETCH_SIZE x2 on gfx950, KiB -> bytes): counters cannot be read live, so the figure carries its
+        # provenance and is dropped when the summary does not contain the kernel this run found dominant.
+        traffic, source = None, None
+        pmc = latest_pmc()
+        if pmc:
+            try:
+                d = json.load(open(pmc))
+                meta = d.get("_meta", {})
+                want = dk.split("(")[0].replace(" ", "")
+                best = 0.0
+                for kname, e in d.items():
+                    if kname == "_meta" or not isinstance(e, dict):
+                        continue
+                    if kname.replace("dsd::", "").replace(" ", "").startswith(want) and e.get("total_us_under_pmc", 0) > best \
+                            and meta.get("precision", "bf16x6") == precision:
+                        best = e["total_us_under_pmc"]
+                        traffic = e.get("hbm_bytes_per_launch")
+                        source = {"file": os.path.relpath(pmc, ROOT), "kernel": kname, "git_head": meta.get("git_head"),
+                                  "command": meta.get("command"), "launches_under_pmc": e.get("launches"),
+                                  "mfma_pipe_util": e.get("mfma_pipe_util"), "effective_clock_GHz": e.get("effective_clock_GHz")}
+            except Exception:
+                traffic, source = None, None
+        alg_bytes = dv["bytes"] / calls
+        roofline = {
+            "bound": "mfma", "kernel": dk,
+            # achieved / peak / frac are PHYSICAL: MFMA FLOPs issued in the dtype the matrix cores run (every fp32
+            # product = `passes` bf16/f16 MFMA products, each counted as 2*MAC) against that dtype's dense peak
+            "achieved": round(alg * passes, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(alg * passes / peak, 4),
+            "issued_dtype": ISSUED_DTYPE[precision], "mfma_products_per_fp32_product": passes,
+            "algorithmic_tflops": round(alg, 2),                        # 2*MAC of the fp32 convolution / time
+            "frac_vs_fp32_mfma_peak": round(alg / PEAK_FP32_MFMA_TFLOPS, 4),   # SURVEY 8d yard-stick (can exceed 1)
+            "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+            "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic and alg_bytes else None,
+            "traffic_source": source,
+            "launches_per_step": dv["calls"] // max(runs, 1), "avg_launch_ms": round(dv["ms"] / calls, 4),
+            "flops_per_launch": dv["flops"] / calls, "share_of_step_time": round(dv["ms"] / tot_ms, 4),
+            "whole_step_algorithmic_tflops": res["whole_step_tflops"],
+            "whole_step_frac_issued": round(res["whole_step_tflops"] * passes / peak, 4),
+            "whole_step_frac_vs_fp32_mfma_peak": round(res["whole_step_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)}
+        kern = {}
+        for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
+            e = {"ms_per_step": round(v["ms"] / runs, 3), "calls_per_step": v["calls"] // runs}
+            if v["flops"] > 0:
+                e["tflops"] = round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2)
+            if v["bytes"] > 0:
+                e["gbs"] = round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1)
+                e["hbm_frac"] = round(e["gbs"] / PEAK_HBM_GBS, 4)
+            kern[k] = e
+        return roofline, kern
+
+
+# ======================================================================================== one rank
+def run_rank(args):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal hooks (never set by the driver): run N ranks on ONE device over gloo to exercise the multi-rank code path
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU"
     backend = os.environ.get("DSD_BENCH_BACKEND", "nccl")
+    stub = bool(os.environ.get("DSD_BENCH_STUB"))
     if os.environ.get("DSD_BENCH_SINGLE_DEVICE"):
         local = 0
+    dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -102,186 +363,109 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(backend)
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-
-    import yaml
-    from diffusion_models_dsdiff_amd import _lib
-    from diffusion_models_dsdiff_amd.ldm.util import instantiate_from_config
-    from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
-    from diffusion_models_dsdiff_amd._sched import run_device_loop
-
-    gpu_name, n_cu, hbm = _lib.require_gpu(local)
-    cfg = yaml.safe_load(open(args.config))
-    mp = cfg["model"]["params"]
-    uc = dict(mp["unet_config"])
-    uc["params"] = dict(uc["params"], device_index=local)
-    if args.model_channels:
-        uc["params"]["model_channels"] = args.model_channels
-    torch.manual_seed(2024)
-    t0 = time.time()
-    model = instantiate_from_config(uc)
-    model.set_precision(args.precision)
-    synth_weights_(model, 2024)
-    n_params = sum(p.numel() for p in model.parameters())
-    # one-off weight distribution: rank 0's parameters broadcast as ONE packed blob over RCCL/xGMI
-    bcast_ms = None
-    if world > 1:
-        flat = torch.cat([p.data.reshape(-1) for p in model.parameters()]).to(dev)
-        torch.cuda.synchronize()
-        tb = time.time()
-        dist.broadcast(flat, 0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.time() - tb) * 1e3
-        off = 0
-        for p in model.parameters():
-            p.data = flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
-    model.sync_params()
-    t_setup = time.time() - t0
-
-    B, H, W = args.batch, args.size, args.size
-    diffusion = create_gaussian_diffusion(steps=mp.get("diffusion_steps", 1000), learn_sigma=mp.get("learn_sigma", False),
-                                          noise_schedule=mp.get("noise_schedule", "linear"),
-                                          predict_xstart=mp.get("predict_xstart", False),
-                                          rescale_timesteps=mp.get("rescale_timesteps", False),
-                                          timestep_respacing=mp.get("timestep_respacing", ""),
-                                          parameterization=mp.get("parameterization", "eps"))
-    sched = diffusion._schedule(False, 0.0, bool(mp.get("clip_denoised", True)))
-    assert sched.steps == 1000
-    g = torch.Generator(device=dev).manual_seed(2025 + rank)
-    cond = torch.randn(B, 1, H, W, device=dev, generator=g).clamp_(-1, 1)
-    x = torch.randn(B, 1, H, W, device=dev, generator=g)
+    leg = (StubLeg if stub else GpuLeg)(args, rank, local, world)
+    dev = leg.dev
 
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        leg.sync()
 
-    peak_bf16 = 2500.0
+    def reduce_max(ms):
+        """MAX over ranks of the per-step time (the job is as slow as its slowest rank) + every rank's own figure."""
+        if world == 1:
+            return ms, [round(ms, 3)]
+        mine = torch.tensor([ms], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        vals = [float(v.item()) for v in allr]
+        return max(vals), [round(v, 3) for v in vals]
 
-    def measure(precision, steps, warmup, profile_steps):
-        """K timed denoising steps in one arithmetic mode (+ optional per-kernel hipEvent pass on rank 0)."""
-        nonlocal x
-        model.set_precision(precision)
-        if warmup > 0:
-            x = run_device_loop(model, sched, x, cond, seed=1234, first_step=0, n_steps=warmup)
-        else:
-            _lib.check(_lib.lib().dsd_plan(model._h, B, 2, H, W))
-        barrier()
-        t1 = time.time()
-        x = run_device_loop(model, sched, x, cond, seed=1234, first_step=warmup, n_steps=steps)
-        barrier()
-        dt = time.time() - t1
-        if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        ms = dt / steps * 1e3
-        info = model.plan_info()
-        res = {"precision": precision, "ms_per_step": round(ms, 3), "value": round((B * world) / (1000.0 * ms / 1e3), 6),
-               "whole_step_tflops": round(info["flops"] / (ms / 1e3) / 1e12, 2), "finite": bool(torch.isfinite(x).all()),
-               "info": info, "roofline": None, "kernels": None}
-        if profile_steps > 0 and rank == 0:
-            model.profile(True)
-            run_device_loop(model, sched, x, cond, seed=1234, first_step=warmup + steps, n_steps=profile_steps)
-            rep, runs = model.profile_report()
-            model.profile(False)
-            tot_ms = sum(v["ms"] for v in rep.values())
-            dk, dv = max(rep.items(), key=lambda kv: kv[1]["ms"])
-            ach = dv["flops"] / (dv["ms"] / 1e3) / 1e12
-            passes = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "f16x3": 3}[precision]
-            traffic = None
-            # HBM bytes per launch from the committed PMC passes of this same command (tools/pmc_summary.py;
-            # separate --pmc runs, FETCH_SIZE x2 on gfx950, KiB -> bytes): counters cannot be read live.
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc.json")
-            if os.path.exists(pmc):
-                try:
-                    want = {"f32": ("conv_mfma_buf_kernel", "<5>"), "bf16x6": ("conv_split", "<5, 3"),
-                            "bf16x3": ("conv_split", "<5, 2, false"), "f16x3": ("conv_split", "<5, 2, true")}[precision]
-                    best = 0.0
-                    for kname, e in json.load(open(pmc)).items():   # the variant with the most time under PMC
-                        if want[0] in kname and want[1] in kname and e.get("total_us_under_pmc", 0) > best:
-                            best = e["total_us_under_pmc"]
-                            traffic = e.get("hbm_bytes_per_launch")
-                except Exception:
-                    traffic = None
-            # achieved = ALGORITHMIC FLOPs (2*MAC of the fp32 convolution) / measured time.  peak = the fp32 matrix peak
-            # in every mode (SURVEY.md 8d: "if bf16x3 is used, still report against fp32 peak and state the bf16 peak"):
-            # the split modes issue `passes` bf16 MFMAs per fp32 product, so frac > 1 is possible there.
-            res["roofline"] = {"bound": "mfma", "kernel": dk, "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                               "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
-                               "peak_note": "fp32-input MFMA dense peak (157.3); bf16 dense MFMA peak is 2500",
-                               "issued_mfma_tflops": round(ach * passes, 1),
-                               "issued_frac_of_issued_dtype_peak": round(ach * passes / (PEAK_FP32_MFMA_TFLOPS if passes == 1 else peak_bf16), 4),
-                               "launches_per_step": dv["calls"] // max(runs, 1),
-                               "avg_launch_ms": round(dv["ms"] / max(dv["calls"], 1), 4),
-                               "flops_per_launch": dv["flops"] / max(dv["calls"], 1),
-                               "share_of_step_time": round(dv["ms"] / tot_ms, 4),
-                               "whole_step_tflops": res["whole_step_tflops"],
-                               "whole_step_frac": round(res["whole_step_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)}
-            kern = {}
-            for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
-                e = {"ms_per_step": round(v["ms"] / runs, 3), "calls_per_step": v["calls"] // runs}
-                if v["flops"] > 0:
-                    e["tflops"] = round(v["flops"] / (v["ms"] / 1e3) / 1e12, 2)
-                if v["bytes"] > 0:
-                    e["gbs"] = round(v["bytes"] / (v["ms"] / 1e3) / 1e9, 1)
-                    e["hbm_frac"] = round(e["gbs"] / PEAK_HBM_GBS, 4)
-                kern[k] = e
-            res["kernels"] = kern
-        return res
-
-    main_res = measure(args.precision, args.steps, args.warmup, 0 if args.no_profile else 2)
+    main_res = leg.measure(args.precision, args.steps, args.warmup, 0 if args.no_profile else 2, barrier, reduce_max)
     ms_per_step, slices_per_s = main_res["ms_per_step"], main_res["value"]
     info, finite, roofline, kernels = main_res["info"], main_res["finite"], main_res["roofline"], main_res["kernels"]
-    # the other arithmetic modes, measured in the same process (single-GPU runs only; 2 steps each)
-    modes = {args.precision: {k: main_res[k] for k in ("ms_per_step", "value", "whole_step_tflops")}}
-    if world == 1 and not args.no_modes:
-        for pr in ("f32", "bf16x6", "f16x3", "bf16x3"):
-            if pr == args.precision:
-                continue
-            r = measure(pr, 2, 1, 0 if args.no_profile else 1)
-            modes[pr] = {k: r[k] for k in ("ms_per_step", "value", "whole_step_tflops")}
-            if r["roofline"]:
-                modes[pr]["dominant_kernel"] = {k: r["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")}
-        model.set_precision(args.precision)
-        # separate line (never part of `value`): the two zero-input streams evaluated once per step instead of per slice
-        model.share_zero_streams(True)
-        r = measure(args.precision, 2, 1, 0)
-        model.share_zero_streams(False)
-        modes[args.precision + "+share_zero_streams"] = {
-            "ms_per_step": r["ms_per_step"], "value": r["value"], "executed_flops_per_step": r["info"]["flops"],
-            "note": "same output up to fp32 rounding; 2 of the 4 encoder streams have all-zero input in the 1->1-channel case and are "
-                    "computed at batch 1 (SURVEY.md 7: must be reported separately)"}
-        _lib.check(_lib.lib().dsd_plan(model._h, B, 2, H, W))
 
-    # separate line (never part of `value`): the 20-evaluation DPM-Solver++ sampler of the reference
-    # (gaussian_diffusion.py:467-522), whole samples end to end through dsd_sample_dpm
-    samplers = None
-    if world == 1 and not args.no_modes:
-        d20 = create_gaussian_diffusion(steps=1000, timestep_respacing="20", rescale_timesteps=True,
-                                        parameterization=mp.get("parameterization", "eps"))
-        x_T = torch.randn(B, 1, H, W, device=dev, generator=g)
+    # end of the job: the samples go to rank 0 (256 KB per slice) — the only other collective on the path
+    gather_ms = None
+    if world > 1:
         barrier()
-        t1 = time.time()
-        y = d20.dpm_solver_sample_loop(model, (B, 1, H, W), model_kwargs=dict(c_concat=[cond]), noise=x_T)
-        barrier()
-        dt = time.time() - t1
-        samplers = {"dpm_solver++_multistep2_20": {
-            "network_evaluations": 20, "seconds_per_batch": round(dt, 3), "slices_per_s": round(B / dt, 4),
-            "ms_per_evaluation": round(dt / 20 * 1e3, 2), "finite": bool(torch.isfinite(y).all()),
-            "note": "logSNR spacing, order 2, dynamic thresholding (radix-select quantile) — a different sampler, not the "
-                    "1000-step metric"}}
+        tg = time.time()
+        parts = [torch.empty_like(leg.x) for _ in range(world)] if rank == 0 else None
+        dist.gather(leg.x, parts, 0)
+        leg.sync()
+        gather_ms = (time.time() - tg) * 1e3
+        if rank == 0 and stub:
+            assert [float(p.flatten()[0]) for p in parts] == [float(r) for r in range(world)]
+    rccl_ranks = dist.get_world_size() if world > 1 else 1
 
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-        cpu = cpu_baseline(uc["params"], sd, H, W, args.cpu_seconds)
+    modes, samplers, cpu, rel = {args.precision: {k: main_res[k] for k in ("ms_per_step", "value", "whole_step_tflops")}}, None, None, None
+    if not stub and world == 1:
+        from diffusion_models_dsdiff_amd import _lib
+        from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
+        model, B, H, W = leg.model, args.batch, args.size, args.size
+        if not args.no_modes:
+            # the other arithmetic modes, measured in the same process (2 steps each)
+            for pr in ("f32", "bf16x6", "f16x3", "bf16x3"):
+                if pr == args.precision:
+                    continue
+                r = leg.measure(pr, 2, 1, 0 if args.no_profile else 1, barrier, reduce_max)
+                modes[pr] = {k: r[k] for k in ("ms_per_step", "value", "whole_step_tflops")}
+                if r["roofline"]:
+                    modes[pr]["dominant_kernel"] = {k: r["roofline"][k] for k in ("kernel", "achieved", "peak", "frac",
+                                                                                  "algorithmic_tflops", "avg_launch_ms")}
+            model.set_precision(args.precision)
+            # separate line (never part of `value`): the two zero-input streams evaluated once per step instead of per slice
+            model.share_zero_streams(True)
+            r = leg.measure(args.precision, 2, 1, 0, barrier, reduce_max)
+            model.share_zero_streams(False)
+            modes[args.precision + "+share_zero_streams"] = {
+                "ms_per_step": r["ms_per_step"], "value": r["value"], "executed_flops_per_step": r["info"]["flops"],
+                "note": "same output up to fp32 rounding; 2 of the 4 encoder streams have all-zero input in the 1->1-channel case and are "
+                        "computed at batch 1 (SURVEY.md 7: must be reported separately)"}
+            # separate line: every kernel launched from the host (no hipGraph replay)
+            if not args.no_graph:
+                model.use_graph(False)
+                r = leg.measure(args.precision, 2, 1, 0, barrier, reduce_max)
+                model.use_graph(True)
+                modes[args.precision + "+no_graph"] = {"ms_per_step": r["ms_per_step"], "value": r["value"]}
+            _lib.check(_lib.lib().dsd_plan(model._h, B, 2, H, W))
+            # separate line (never part of `value`): the 20-evaluation DPM-Solver++ sampler of the reference
+            # (gaussian_diffusion.py:467-522), whole samples end to end through dsd_sample_dpm
+            d20 = create_gaussian_diffusion(steps=1000, timestep_respacing="20", rescale_timesteps=True,
+                                            parameterization=leg.mp.get("parameterization", "eps"))
+            x_T = torch.randn(B, 1, H, W, device=dev, generator=leg.g)
+            barrier()
+            t1 = time.time()
+            y = d20.dpm_solver_sample_loop(model, (B, 1, H, W), model_kwargs=dict(c_concat=[leg.cond]), noise=x_T)
+            barrier()
+            dt = time.time() - t1
+            samplers = {"dpm_solver++_multistep2_20": {
+                "network_evaluations": 20, "seconds_per_batch": round(dt, 3), "slices_per_s": round(B / dt, 4),
+                "ms_per_evaluation": round(dt / 20 * 1e3, 2), "finite": bool(torch.isfinite(y).all()),
+                "note": "logSNR spacing, order 2, dynamic thresholding (radix-select quantile) — a different sampler, not the "
+                        "1000-step metric"}}
+        if args.cpu_seconds > 0:
+            # CPU leg: the oracle timed on this host AND used as the checker of the GPU path on the same input, same run
+            sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+            cpu, x1, t1_, y_cpu = cpu_baseline(leg.unet_params, sd, H, W, args.cpu_seconds)
+            model.set_precision(args.precision)
+            y_gpu = model._run(x1.to(dev), t1_.to(dev), want_feats=False)[0].cpu()
+            err = float((y_gpu.double() - y_cpu.double()).norm() / y_cpu.double().norm())
+            rel = {f"forward_{H}": err, "mode": args.precision, "tolerance": 1e-4,
+                   "what": f"one forward of the same network at {H}x{W}, batch 1, seeded input, t = 500: GPU path ({args.precision}) "
+                           "vs the fp32 CPU oracle whose timing is cpu_baseline; tests/test_model_gpu.py::test_full_size_vs_oracle "
+                           "adds the last steps of the 1000-step chain and a row of a batch-16 forward"}
+            _lib.check(_lib.lib().dsd_plan(model._h, B, 2, H, W))
 
     if rank == 0:
+        B, H, W = args.batch, args.size, args.size
+        headline = (B == HEADLINE["batch"] and H == HEADLINE["size"] and args.model_channels is None and not stub
+                    and os.path.abspath(args.config) == os.path.join(ROOT, "configs", "v2-1-cddpm-ds-disc.yaml"))
+        net = "v2-1-cddpm-ds-disc.yaml U-Net" + (f" with model_channels={args.model_channels}" if args.model_channels else "")
+        workload = (f"{'configs[1]: ' if headline else 'DEBUG OVERRIDE (not a BASELINE config): '}{net}, {H}x{W} 1->1-ch, "
+                    f"1000-step DDPM, batch {B} per GPU; a step = 1 of the 1000 denoising steps for the whole batch")
         out = {
-            "metric": "256x256 cDDPM slices/sec (1000-step)",
+            "metric": "256x256 cDDPM slices/sec (1000-step)" if headline else None,
             "value": round(slices_per_s, 6),
             "unit": "slices/s",
             "n_gpus": world,
@@ -294,26 +478,43 @@ def main():
             "dtype": {"f32": "f32", "bf16x6": "f32 (operands split exactly into 3 bf16 pieces, 6 bf16-MFMA products, f32 accumulate)",
                       "bf16x3": "bf16x3 (2 bf16 pieces per f32 operand, 3 products, f32 accumulate)",
                       "f16x3": "f16x3 (2 fp16 pieces per f32 operand, 3 products, f32 accumulate)"}[args.precision],
-            "data": "synthetic",
-            "config": {"workload": "configs[1]: v2-1-cddpm-ds-disc.yaml U-Net, 256x256 1->1-ch, 1000-step DDPM, "
-                                   f"batch {B} per GPU; a step = 1 of the 1000 denoising steps for the whole batch",
-                       "slices_per_gpu": B, "image": [H, W], "sampler": "guided-diffusion DDPM, v-param, 1000 steps",
-                       "params": n_params, "sharding": f"slices x{world} (no data-path collective)"},
+            "data": "synthetic" if not stub else "STUB (no GPU work: launcher rehearsal)",
+            "config": {"workload": workload, "slices_per_gpu": B, "image": [H, W],
+                       "sampler": "guided-diffusion DDPM, v-param, 1000 steps", "params": leg.n_params,
+                       "sharding": f"slices x{world} (no data-path collective)"},
+            "rel_l2_vs_cpu": rel,
             "roofline": roofline,
             "cpu_baseline": cpu,
+            "rccl_ranks": rccl_ranks,
+            "per_rank_ms_per_step": main_res["per_rank_ms_per_step"],
+            "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "kernels": kernels,
             "modes": modes,
             "samplers": samplers,
-            "extra": {"gpu": gpu_name, "compute_units": n_cu, "finite_output": finite,
+            "extra": {"gpu": leg.gpu_name, "compute_units": leg.n_cu, "finite_output": finite,
                       "workspace_GiB": round(info["workspace_bytes"] / 2 ** 30, 2), "launches_per_step": info["launches"],
                       "executed_flops_per_step": info["flops"],
                       "survey_flops_per_step": F_LIVE_PER_SLICE_STEP * B,
+                      "hip_graph": (not args.no_graph) and not stub,
+                      "launched_by": "self (bench.py --gpus N)" if os.environ.get("DSD_BENCH_LAUNCHED_BY_PARENT") else
+                                     ("torch.distributed.run" if world > 1 else "single process"),
+                      "backend": backend if world > 1 else None,
                       "seconds_per_1000_step_batch": round(ms_per_step, 3),
-                      "setup_s": round(t_setup, 1), "weight_broadcast_ms": bcast_ms},
+                      "setup_s": round(leg.t_setup, 1), "weight_broadcast_ms": leg.bcast_ms},
         }
-        print(json.dumps(out))
+        if not headline:
+            out["valid_for_baseline"] = False
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -69,21 +69,19 @@ class SpacedDiffusion(GaussianDiffusion):
     def _wrap_model(self, model):
         if isinstance(model, _WrappedModel):
             return model
-        return _WrappedModel(model, self.timestep_map, self.rescale_timesteps, self.original_num_steps)
+        return _WrappedModel(model, self._model_timestep_values(), self.rescale_timesteps)
 
 
 class _WrappedModel:
-    """respace.py:116-128 (kept for callers that wrap a model themselves)."""
+    """Callers that wrap a model themselves (the role of respace.py:116-128): the network sees the ORIGINAL process's
+    timestep for loop index ``ts``.  The lookup table is the one the device loop uploads (_model_timestep_values), so both
+    paths hand the network identical values: int64 indices when the timesteps are not rescaled, fp32 otherwise."""
 
-    def __init__(self, model, timestep_map, rescale_timesteps, original_num_steps):
+    def __init__(self, model, timestep_values, rescale_timesteps):
         self.model = model
-        self.timestep_map = timestep_map
-        self.rescale_timesteps = rescale_timesteps
-        self.original_num_steps = original_num_steps
+        self.rescale_timesteps = bool(rescale_timesteps)
+        self._values = th.from_numpy(np.ascontiguousarray(timestep_values, dtype=np.float32))
 
     def __call__(self, x, ts, **kwargs):
-        map_tensor = th.tensor(self.timestep_map, device=ts.device, dtype=ts.dtype)
-        new_ts = map_tensor[ts]
-        if self.rescale_timesteps:
-            new_ts = new_ts.float() * (1000.0 / self.original_num_steps)
-        return self.model(x, new_ts, **kwargs)
+        values = self._values.to(ts.device)[ts.long()]
+        return self.model(x, values if self.rescale_timesteps else values.long(), **kwargs)

@@ -85,16 +85,71 @@ class NativeModule(nn.Module):
         check(lib().dsd_set_share_zero_streams(self._h, int(on)))
         return self
 
+    def use_graph(self, on: bool = True):
+        """Replay the captured hipGraph of a denoising step inside sampling loops (default) or launch every kernel from
+        the host (include/dsdiff.h: dsd_set_graph)."""
+        check(lib().dsd_set_graph(self._h, int(on)))
+        return self
+
+    def graph_stats(self):
+        c, l = C.c_int(), C.c_int()
+        check(lib().dsd_graph_stats(self._h, C.byref(c), C.byref(l)))
+        return {"captures": c.value, "launches": l.value}
+
+    def set_slice_ids(self, ids=None):
+        """Global slice index of every row of the next sampling batches: keys the on-device noise by slice, not by batch
+        position (include/dsdiff.h: dsd_set_slice_ids).  None clears."""
+        ids = [] if ids is None else [int(i) for i in ids]
+        arr = (C.c_int64 * max(1, len(ids)))(*ids)
+        check(lib().dsd_set_slice_ids(self._h, arr, len(ids)))
+        return self
+
     @property
     def precision(self) -> str:
         code = lib().dsd_get_precision(self._h)
         return {v: k for k, v in _lib.PRECISIONS.items()}[code]
 
-    def sync_params(self, force: bool = False):
-        """Upload parameters that changed since the last upload (load_state_dict, .to(), in-place edits)."""
-        L = lib()
+    # ---- change detection ---------------------------------------------------------------------------
+    # (data_ptr, _version, device) catches load_state_dict, .to(), optimiser steps and every in-place op on the parameter
+    # itself.  Edits through ``p.data`` (``p.data.copy_(ema)``, ``p.data.normal_()`` — the idiom of the reference's
+    # LitEma.copy_to / ema_scope weight swaps, ldm/modules/ema.py) bump neither, so a sparse value fingerprint (three
+    # elements per parameter) is compared as well: a swap or re-initialisation changes every element, so it cannot hide
+    # from it.  An edit that leaves those three elements untouched needs mark_dirty() / sync_params(force=True).
+    @staticmethod
+    def _probe_index(numel):
+        return (0, numel // 2, numel - 1) if numel > 0 else ()
+
+    def _fingerprints(self):
+        """{name: (v0, v_mid, v_last)}; CPU parameters are read through their address, CUDA ones with one gather."""
+        out, cuda = {}, []
         for nm, p in self.named_parameters():
-            key = (p.data_ptr(), p._version, p.device.type)
+            n = p.numel()
+            if n == 0:
+                out[nm] = ()
+            elif p.device.type == "cpu" and p.dtype == torch.float32 and p.is_contiguous():
+                base = p.data_ptr()
+                out[nm] = tuple(C.c_float.from_address(base + 4 * i).value for i in self._probe_index(n))
+            else:
+                cuda.append((nm, p))
+        if cuda:
+            vals = torch.stack([p.detach().reshape(-1)[list(self._probe_index(p.numel()))].float() for _, p in cuda]).cpu()
+            for (nm, _), v in zip(cuda, vals):
+                out[nm] = tuple(float(x) for x in v)
+        return out
+
+    def mark_dirty(self, names=None):
+        """Force the next sync_params() to re-upload `names` (default: every parameter)."""
+        for nm in (list(self._uploaded) if names is None else names):
+            self._uploaded.pop(nm, None)
+
+    def sync_params(self, force: bool = False):
+        """Upload parameters that changed since the last upload: load_state_dict, .to(), in-place ops on the parameter
+        (version counter) and in-place edits through ``.data`` (value fingerprint, see above).  ``force=True`` re-uploads
+        everything unconditionally."""
+        L = lib()
+        fps = self._fingerprints()
+        for nm, p in self.named_parameters():
+            key = (p.data_ptr(), p._version, p.device.type, fps[nm])
             if not force and self._uploaded.get(nm) == key:
                 continue
             t = p.detach()
@@ -254,7 +309,7 @@ class DSUnetModel(NativeModule):
     def plan_info(self):
         L = lib()
         return {"workspace_bytes": int(L.dsd_workspace_bytes(self._h)), "launches": int(L.dsd_plan_launches(self._h)),
-                "flops": float(L.dsd_plan_flops(self._h))}
+                "flops": float(L.dsd_plan_flops(self._h)), "device_bytes": int(L.dsd_device_bytes(self._h))}
 
     def profile(self, on: bool):
         """Per-kernel hipEvent timing of every op of the plan (dsd_profile_enable)."""

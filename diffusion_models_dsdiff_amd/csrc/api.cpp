@@ -180,8 +180,11 @@ int dsd_set_precision(dsd_handle* h, int precision) {
     DSD_CHECK(h, "null handle");
     DSD_CHECK(precision >= PREC_F32 && precision <= PREC_F16X3, "unknown precision %d", precision);
     if (h->precision != precision) {
+        set_device(h->device);
         h->precision = precision;
         h->plan.valid = false;   // the plan bakes the kernel choice in
+        net_drop_graph(h);
+        net_drop_other_pieces(h, precision);   // bf16 and fp16 pieces (6 B per weight each) are never both resident
     }
     DSD_CATCH
 }
@@ -212,6 +215,50 @@ int dsd_plan(dsd_handle* h, int B, int C, int H, int W) {
 }
 
 int64_t dsd_workspace_bytes(dsd_handle* h) { return h && h->plan.valid ? (int64_t)h->plan.arena_bytes : -1; }
+
+int64_t dsd_device_bytes(dsd_handle* h) {
+    if (!h) return -1;
+    return (int64_t)(h->slab_bytes + h->staging_bytes + h->arena_cap + net_piece_bytes(h) + h->tbuf_cap + h->mout_cap +
+                     h->zplane_cap + h->dpm_m_cap);
+}
+
+int dsd_set_graph(dsd_handle* h, int on) {
+    DSD_TRY
+    DSD_CHECK(h, "null handle");
+    h->use_graph = on != 0;
+    if (!on) {
+        set_device(h->device);
+        net_drop_graph(h);
+    }
+    DSD_CATCH
+}
+
+int dsd_graph_stats(dsd_handle* h, int* captures, int* launches) {
+    DSD_TRY
+    DSD_CHECK(h, "null handle");
+    if (captures) *captures = h->graph_captures;
+    if (launches) *launches = h->graph_launches;
+    DSD_CATCH
+}
+
+int dsd_set_slice_ids(dsd_handle* h, const int64_t* ids_host, int n) {
+    DSD_TRY
+    DSD_CHECK(h && !h->is_block && n >= 0 && (ids_host || n == 0), "bad argument");
+    set_device(h->device);
+    if (h->slice_ids) {
+        DSD_HIP(hipDeviceSynchronize());
+        DSD_HIP(hipFree(h->slice_ids));
+        h->slice_ids = nullptr;
+    }
+    h->n_slice_ids = 0;
+    if (n > 0) {
+        for (int i = 0; i < n; ++i) DSD_CHECK(ids_host[i] >= 0, "slice id %d is negative", i);
+        DSD_HIP(hipMalloc((void**)&h->slice_ids, (size_t)n * sizeof(int64_t)));
+        DSD_HIP(hipMemcpy(h->slice_ids, ids_host, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+        h->n_slice_ids = n;
+    }
+    DSD_CATCH
+}
 int dsd_plan_launches(dsd_handle* h) { return h && h->plan.valid ? h->plan.launches : -1; }
 double dsd_plan_flops(dsd_handle* h) { return h && h->plan.valid ? h->plan.flops : -1.0; }
 
@@ -221,7 +268,7 @@ int dsd_forward(dsd_handle* h, const float* x, const void* t, int t_is_float, in
     DSD_CHECK(h && !h->is_block && x && t && out, "null argument");
     set_device(h->device);
     hipStream_t s = (hipStream_t)stream;
-    net_plan(h, B, C, H, W, C == 2, feats != nullptr, 0, 0);
+    net_plan(h, B, C, H, W, C == 2, feats != nullptr, 0, 0, 0, s);
     bind_planes(h, x, C, H, W, s);
     h->io.t = t;
     h->io.t_is_float = t_is_float;
@@ -263,7 +310,7 @@ int dsd_block_forward(dsd_handle* h, const float* x, int B, int C, int H, int W,
     DSD_TRY
     DSD_CHECK(h && h->is_block && x && out, "null argument / not a block handle");
     set_device(h->device);
-    net_plan(h, B, C, H, W, 0, 0, aux ? aux_len : 0, aux2 ? aux_len2 : 0);
+    net_plan(h, B, C, H, W, 0, 0, aux ? aux_len : 0, aux2 ? aux_len2 : 0, 0, (hipStream_t)stream);
     h->io.x_nchw = x;
     h->io.aux = aux;
     h->io.aux2 = aux2;
@@ -323,17 +370,20 @@ int dsd_sample(dsd_handle* h, const dsd_schedule* sc, const float* cond, int Cc,
     set_device(h->device);
     hipStream_t s = (hipStream_t)stream;
     const int64_t hw = (int64_t)H * W;
-    net_plan(h, B, Cc + 1, H, W, Cc == 1, 0, 0, 0, (Cc == 1 && B > 1) ? h->share_zero_streams : 0);
+    net_plan(h, B, Cc + 1, H, W, Cc == 1, 0, 0, 0, (Cc == 1 && B > 1) ? h->share_zero_streams : 0, s);
     ensure_buf(&h->tbuf, &h->tbuf_cap, (size_t)B * sizeof(float));
     ensure_buf(&h->mout, &h->mout_cap, (size_t)B * out_ch * hw * sizeof(float));
     bind_sampling_io(h, x, cond, Cc, hw, s);
+    DSD_CHECK(h->n_slice_ids == 0 || h->n_slice_ids == B, "dsd_set_slice_ids gave %d ids but the batch has %d slices", h->n_slice_ids, B);
+    const int64_t* ids = h->n_slice_ids == B ? h->slice_ids : nullptr;
     const int k0 = first_step < 0 ? 0 : first_step;
     const int k1 = n_steps <= 0 ? sc->steps : std::min(sc->steps, k0 + n_steps);
     for (int k = k0; k < k1; ++k) {
         fill_t(h->tbuf, B, sc->t_model[k], s);
-        net_run(h, s);
+        net_run_cached(h, s);
         const StepCoef c = step_coef(sc, k);
-        sampler_update(c, h->mout, x, noise ? noise + (size_t)k * B * hw : nullptr, philox_seed, (uint64_t)k, B, (int)hw, s);
+        sampler_update(c, h->mout, x, noise ? noise + (size_t)k * B * hw : nullptr, philox_seed, (uint64_t)k, B, (int)hw, s,
+                       nullptr, ids);
     }
     net_check_overflow(h, s);
     DSD_CATCH
@@ -382,7 +432,7 @@ int dsd_sample_dpm(dsd_handle* h, const dsd_dpm_schedule* sc, const float* cond,
     set_device(h->device);
     hipStream_t s = (hipStream_t)stream;
     const int64_t hw = (int64_t)H * W;
-    net_plan(h, B, Cc + 1, H, W, Cc == 1, 0, 0, 0, (Cc == 1 && B > 1) ? h->share_zero_streams : 0);
+    net_plan(h, B, Cc + 1, H, W, Cc == 1, 0, 0, 0, (Cc == 1 && B > 1) ? h->share_zero_streams : 0, s);
     ensure_buf(&h->tbuf, &h->tbuf_cap, (size_t)B * sizeof(float));
     ensure_buf(&h->mout, &h->mout_cap, (size_t)B * out_ch * hw * sizeof(float));
     ensure_buf(&h->dpm_m, &h->dpm_m_cap, ((size_t)2 * B * hw + B) * sizeof(float));
@@ -392,7 +442,7 @@ int dsd_sample_dpm(dsd_handle* h, const dsd_dpm_schedule* sc, const float* cond,
     float* s_buf = h->dpm_m + (size_t)2 * B * hw;
     for (int k = 0; k < sc->steps; ++k) {
         fill_t(h->tbuf, B, sc->t_input[k], s);
-        net_run(h, s);
+        net_run_cached(h, s);
         dpm_step(dpm_coef(sc, k), h->mout, out_ch, x, m_cur, m_prev, s_buf, sc->threshold_ratio, sc->threshold_max, B, (int)hw, s);
         std::swap(m_cur, m_prev);
     }
@@ -569,9 +619,9 @@ int dsd_op_qkv_attention(const float* qkv, int N, int T, int C, int heads, int n
     DSD_CATCH
 }
 
-int dsd_op_timestep_embedding(const void* t, int t_is_float, int N, int dim, float* y, void* stream) {
+int dsd_op_timestep_embedding(const void* t, int t_is_float, int N, int dim, const float* freqs, float* y, void* stream) {
     DSD_TRY
-    timestep_embedding(t, t_is_float, N, dim, y, (hipStream_t)stream);
+    timestep_embedding(t, t_is_float, N, dim, y, (hipStream_t)stream, freqs);
     DSD_CATCH
 }
 

@@ -93,8 +93,10 @@ struct StepCoef {
     float eta;
 };
 // model_out: [B,Cm,HW] (Cm = 1, or 2 with learned_range); x in/out [B,1,HW]; noise [B,1,HW] or null (Philox)
+// slice_ids (optional, device [B]): global slice index of every batch row — the Philox counter of element p of row b is
+// slice_ids[b]*HW + p instead of b*HW + p, so a slice's noise does not depend on how the volume was sharded or batched
 void sampler_update(const StepCoef& sc, const float* model_out, float* x, const float* noise, uint64_t seed,
-                    uint64_t step, int B, int HW, hipStream_t s, float* x0_out = nullptr);
+                    uint64_t step, int B, int HW, hipStream_t s, float* x0_out = nullptr, const int64_t* slice_ids = nullptr);
 // DPM-Solver(++) multistep: coefficients of one network evaluation + update (host tables, include/dsdiff.h dsd_dpm_schedule)
 struct DpmCoef {
     float alpha, sigma;      // marginal alpha_t, sigma_t at the evaluation time

@@ -373,6 +373,9 @@ void dsd::net_set_param(dsd_handle* h, const char* name, const float* src, const
         if (!src_is_device) DSD_HIP(hipStreamSynchronize(s));
     }
     p.set = true;
+    // plan-time consumers of the slab (weight splitting) may run on another stream: they wait on this event
+    if (!h->param_ev) DSD_HIP(hipEventCreateWithFlags(&h->param_ev, hipEventDisableTiming));
+    DSD_HIP(hipEventRecord(h->param_ev, s));
     const std::string conv_name = p.name.size() > 7 ? p.name.substr(0, p.name.size() - 7) : p.name;   // "<conv>.weight" -> "<conv>"
     for (const std::string& key : {conv_name, conv_name + "#f16"}) {
         auto sp = h->wsplit.find(key);
@@ -380,9 +383,45 @@ void dsd::net_set_param(dsd_handle* h, const char* name, const float* src, const
             DSD_HIP(hipDeviceSynchronize());
             (void)hipFree(sp->second);
             h->wsplit.erase(sp);
+            h->wsplit_bytes.erase(key);
             h->plan.valid = false;
+            net_drop_graph(h);
         }
     }
+}
+
+void dsd::net_drop_graph(dsd_handle* h) {
+    if (h->gexec) {
+        (void)hipDeviceSynchronize();
+        (void)hipGraphExecDestroy(h->gexec);
+        h->gexec = nullptr;
+    }
+    h->gkey = GraphKey{};
+}
+
+void dsd::net_drop_other_pieces(dsd_handle* h, int precision) {
+    if (precision == PREC_F32) return;   // the exact mode needs none, but switching back should not re-split everything
+    const bool keep_f16 = precision == PREC_F16X3;
+    bool any = false;
+    for (auto it = h->wsplit.begin(); it != h->wsplit.end();) {
+        const bool is_f16 = it->first.size() > 4 && it->first.compare(it->first.size() - 4, 4, "#f16") == 0;
+        if (is_f16 != keep_f16) {
+            if (!any) DSD_HIP(hipDeviceSynchronize());
+            any = true;
+            (void)hipFree(it->second);
+            h->wsplit_bytes.erase(it->first);
+            it = h->wsplit.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    if (any) net_drop_graph(h);
+}
+
+size_t dsd::net_piece_bytes(const dsd_handle* h) {
+    size_t b = 0;
+    for (const auto& kv : h->wsplit_bytes) b += kv.second;
+    return b;
 }
 
 void dsd::net_free(dsd_handle* h) {
@@ -395,8 +434,13 @@ void dsd::net_free(dsd_handle* h) {
     if (h->dpm_m) (void)hipFree(h->dpm_m);
     if (h->freqs) (void)hipFree(h->freqs);
     if (h->ovf) (void)hipFree(h->ovf);
+    if (h->slice_ids) (void)hipFree(h->slice_ids);
+    if (h->param_ev) (void)hipEventDestroy(h->param_ev);
+    if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
+    if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     for (auto& kv : h->wsplit) (void)hipFree(kv.second);
     h->wsplit.clear();
+    h->wsplit_bytes.clear();
     for (auto e : h->ev) (void)hipEventDestroy(e);
     h->ev.clear();
 }
@@ -416,7 +460,9 @@ struct Builder {
     Plan& plan;
     ArenaPlanner ar;
     int B;
-    Builder(dsd_handle* h, Plan& p, int b) : hd(h), plan(p), B(b) {}
+    hipStream_t ps;          // plan-time device work (weight pieces) goes on the caller's stream
+    bool split_any = false;
+    Builder(dsd_handle* h, Plan& p, int b, hipStream_t s) : hd(h), plan(p), B(b), ps(s) {}
 
     Tn alloc(int n, int h, int w, int c) {
         Tn t;
@@ -485,9 +531,11 @@ struct Builder {
                     DSD_HIP(hipMalloc((void**)&hd->ovf, sizeof(int)));
                     DSD_HIP(hipMemset(hd->ovf, 0, sizeof(int)));
                 }
-                split_weights(a.w, pw.numel, 3, planes, nullptr, f16, hd->ovf);
-                DSD_HIP(hipStreamSynchronize(nullptr));
+                // on the caller's stream: ordered after the dsd_set_param copies / repacks enqueued there
+                split_weights(a.w, pw.numel, 3, planes, ps, f16, hd->ovf);
+                split_any = true;
                 it = hd->wsplit.emplace(key, planes).first;
+                hd->wsplit_bytes[key] = (size_t)pw.numel * 2 * 3;
             }
             a.w_split = it->second;
             a.precision = hd->precision;
@@ -1099,7 +1147,7 @@ void build_block(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
 }  // namespace
 
 void dsd::net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int want_feats, int aux_len, int aux_len2,
-                   int share) {
+                   int share, hipStream_t s) {
     Plan& p = h->plan;
     if (p.valid && p.B == B && p.C == C && p.H == H && p.W == W && p.zero_al_l == zero_al_l && p.want_feats == want_feats &&
         p.aux_len == aux_len && p.aux_len2 == aux_len2 && p.share == share)
@@ -1107,10 +1155,14 @@ void dsd::net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int
     DSD_CHECK(h->device >= 0, "this handle was created without a device (table only)");
     for (const auto& prm : h->params) DSD_CHECK(prm.set, "parameter '%s' has not been set", prm.name.c_str());
     DSD_CHECK(B >= 1 && H >= 1 && W >= 1, "empty input");
+    const int gen = p.gen + 1;
+    net_drop_graph(h);
     p = Plan{};
+    p.gen = gen;
     p.B = B; p.C = C; p.H = H; p.W = W; p.zero_al_l = zero_al_l; p.want_feats = want_feats;
     p.aux_len = aux_len; p.aux_len2 = aux_len2; p.share = share;
-    Builder b(h, p, B);
+    if (h->param_ev) DSD_HIP(hipStreamWaitEvent(s, h->param_ev, 0));   // uploads enqueued on any stream have landed first
+    Builder b(h, p, B, s);
     if (h->is_block)
         build_block(b, C, H, W, aux_len, aux_len2);
     else
@@ -1124,6 +1176,7 @@ void dsd::net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int
         DSD_HIP(hipMalloc((void**)&h->arena, p.arena_bytes));
         h->arena_cap = p.arena_bytes;
     }
+    if (b.split_any) DSD_HIP(hipStreamSynchronize(s));   // plan time only: the pieces exist before any stream may use them
     p.valid = true;
 }
 
@@ -1132,6 +1185,7 @@ void dsd::net_run(dsd_handle* h, hipStream_t s) {
     Plan& p = h->plan;
     if (!h->profiling) {
         for (auto& f : p.ops) f(s);
+        ++p.eager_runs;
         return;
     }
     // profiling pass: one event pair per op on the launch stream, read back after a stream sync
@@ -1176,4 +1230,64 @@ void dsd::net_check_overflow(dsd_handle* h, hipStream_t s) {
         DSD_HIP(hipMemsetAsync(h->ovf, 0, sizeof(int), s));
         fail("f16x3: a convolution operand exceeded the fp16 range (|x| > 65504); the result is invalid - use bf16x6 or f32");
     }
+}
+
+// --------------------------------------------------------------------------------------------- whole-forward hipGraph
+// The plan is a fixed list of launches whose arguments depend only on the plan and on the pointers bound in io, so a
+// sampling loop (same buffers every step) replays ONE captured graph per step instead of ~1000 host launches (a22: the
+// reference's Python loop, gaussian_diffusion.py:569-616).  Capture runs the same closures on a library-owned stream (the
+// caller's may be the legacy NULL stream, which cannot be captured) after the plan's first host-launched forward, so lazy
+// code-object loading and any first-use initialisation have happened; the instantiated graph is launched on the caller's
+// stream.  Profiling and the f16x3 overflow check keep working: profiling bypasses the graph, the flag is read after it.
+static GraphKey graph_key(const dsd_handle* h) {
+    GraphKey k;
+    k.plan_gen = h->plan.gen;
+    for (int i = 0; i < 4; ++i) {
+        k.ptr[i] = h->io.plane[i];
+        k.bs[i] = h->io.plane_bs[i];
+    }
+    k.ptr[4] = h->io.t; k.ptr[5] = h->io.out; k.ptr[6] = h->io.feats; k.ptr[7] = h->io.x_nchw; k.ptr[8] = h->io.aux;
+    k.ptr[9] = h->io.aux2; k.ptr[10] = h->arena; k.ptr[11] = h->freqs;
+    k.t_is_float = h->io.t_is_float;
+    return k;
+}
+
+void dsd::net_run_cached(dsd_handle* h, hipStream_t s) {
+    DSD_CHECK(h->plan.valid, "no plan");
+    if (!h->use_graph || h->profiling || h->io.feats) {
+        net_run(h, s);
+        return;
+    }
+    const GraphKey key = graph_key(h);
+    if (h->gexec && key == h->gkey) {
+        DSD_HIP(hipGraphLaunch(h->gexec, s));
+        ++h->graph_launches;
+        return;
+    }
+    if (h->plan.eager_runs == 0) {   // first forward of a plan: from the host (loads code objects, warms the caches)
+        net_run(h, s);
+        return;
+    }
+    net_drop_graph(h);
+    if (!h->cap_stream) DSD_HIP(hipStreamCreateWithFlags(&h->cap_stream, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    DSD_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
+    try {
+        for (auto& f : h->plan.ops) f(h->cap_stream);
+    } catch (...) {
+        (void)hipStreamEndCapture(h->cap_stream, &graph);
+        if (graph) (void)hipGraphDestroy(graph);
+        throw;
+    }
+    DSD_HIP(hipStreamEndCapture(h->cap_stream, &graph));
+    hipError_t e = hipGraphInstantiate(&h->gexec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) {
+        h->gexec = nullptr;
+        fail("hipGraphInstantiate failed: %s", hipGetErrorString(e));
+    }
+    h->gkey = key;
+    ++h->graph_captures;
+    DSD_HIP(hipGraphLaunch(h->gexec, s));
+    ++h->graph_launches;
 }

@@ -64,6 +64,22 @@ struct Plan {
     size_t arena_bytes = 0;
     double flops = 0.0;
     int launches = 0;
+    int gen = 0;          // bumped every time the plan is rebuilt (a captured graph of an older plan is stale)
+    int eager_runs = 0;   // forwards launched from the host since the plan was built (capture waits for the first one)
+};
+
+// What a captured forward bakes in besides the plan: every pointer the closures read from dsd_handle::io.
+struct GraphKey {
+    int plan_gen = -1;
+    const void* ptr[12] = {};
+    int64_t bs[4] = {};
+    int t_is_float = 0;
+    bool operator==(const GraphKey& o) const {
+        if (plan_gen != o.plan_gen || t_is_float != o.t_is_float) return false;
+        for (int i = 0; i < 12; ++i) if (ptr[i] != o.ptr[i]) return false;
+        for (int i = 0; i < 4; ++i) if (bs[i] != o.bs[i]) return false;
+        return true;
+    }
 };
 
 struct dsd_net;
@@ -97,12 +113,23 @@ struct dsd_handle {
     float* zplane = nullptr;   // [H*W] zeros
     float* dpm_m = nullptr;    // dsd_sample_dpm: m_k, m_{k-1} [B,H*W] each + thresholds [B]
     float* freqs = nullptr;    // [model_channels/2] optional timestep-embedding frequency table (host-supplied)
+    int64_t* slice_ids = nullptr;  // [n_slice_ids] global slice index of every batch row (Philox counter base), optional
+    int n_slice_ids = 0;
+    // whole-forward hipGraph (sampling loops): captured on cap_stream after the first host-launched forward of a plan,
+    // replayed on the caller's stream while plan + bound pointers stay the same
+    hipEvent_t param_ev = nullptr;   // recorded after every dsd_set_param on the stream it used
+    int use_graph = 1;
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    dsd::GraphKey gkey;
+    int graph_launches = 0, graph_captures = 0;
     // arithmetic mode of the convolutions (PREC_*): bf16 pieces of each conv weight are made lazily at plan time
     int precision = dsd::PREC_BF16X6;
     // dsd_sample only: evaluate the two all-zero-input streams of the C_in = 2 branch ONCE per step instead of once per
     // slice (same input, same timestep for every slice of the batch -> same result).  Off by default.
     int share_zero_streams = 0;
-    std::unordered_map<std::string, void*> wsplit;   // parameter name -> [3][numel] bf16 planes
+    std::unordered_map<std::string, void*> wsplit;   // parameter name (+"#f16") -> [3][numel] bf16 / fp16 planes
+    std::unordered_map<std::string, size_t> wsplit_bytes;
     int* ovf = nullptr;                              // device flag: fp16 range exceeded in f16x3 mode
     // per-kernel profiling (dsd_profile_*): hipEvents around every op of the plan on the caller's stream
     bool profiling = false;
@@ -121,9 +148,17 @@ namespace dsd {
 void net_declare_params(dsd_handle* h);
 void net_set_param(dsd_handle* h, const char* name, const float* src, const int64_t* shape, int ndim, int src_is_device,
                    hipStream_t s);
+// s: the caller's stream — plan-time device work (splitting the weights into bf16 / fp16 pieces) is ordered after the
+// parameter uploads the caller enqueued on it
 void net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int want_feats, int aux_len, int aux_len2,
-              int share = 0);
+              int share = 0, hipStream_t s = nullptr);
 void net_run(dsd_handle* h, hipStream_t s);
+// the same forward through the captured hipGraph when one is valid for the current plan and bindings (sampling loops)
+void net_run_cached(dsd_handle* h, hipStream_t s);
+void net_drop_graph(dsd_handle* h);
+// frees the weight pieces of the arithmetic family (bf16 / fp16) that `precision` does not use
+void net_drop_other_pieces(dsd_handle* h, int precision);
+size_t net_piece_bytes(const dsd_handle* h);
 // f16x3 only: synchronises the stream and throws if an operand left the fp16 range during the work enqueued so far
 void net_check_overflow(dsd_handle* h, hipStream_t s);
 void net_free(dsd_handle* h);

@@ -63,7 +63,7 @@ void philox_normal(float* y, int64_t n, uint64_t seed, uint64_t step, hipStream_
 __global__ __launch_bounds__(256) void sampler_update_kernel(StepCoef sc, const float* __restrict__ mo,
                                                              float* __restrict__ x, const float* __restrict__ noise,
                                                              uint64_t seed, uint64_t step, int B, int HW,
-                                                             float* __restrict__ x0_out) {
+                                                             float* __restrict__ x0_out, const int64_t* __restrict__ slice_ids) {
     const int64_t total = (int64_t)B * HW;
     const int Cm = sc.learned_range ? 2 : 1;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void sampler_update_kernel(StepCoef sc, const 
         const int64_t p = i - b * HW;
         const float out = mo[(b * Cm) * HW + p];
         const float xt = x[i];
-        const float z = noise ? noise[i] : philox_normal_at(i, seed, step);
+        const float z = noise ? noise[i] : philox_normal_at(slice_ids ? slice_ids[b] * HW + p : i, seed, step);
         const float* c = sc.c;
         float x0, res;
         if (sc.mode == DSD_MODE_B_DDIM) {
@@ -121,11 +121,11 @@ __global__ __launch_bounds__(256) void sampler_update_kernel(StepCoef sc, const 
 }
 
 void sampler_update(const StepCoef& sc, const float* model_out, float* x, const float* noise, uint64_t seed,
-                    uint64_t step, int B, int HW, hipStream_t s, float* x0_out) {
+                    uint64_t step, int B, int HW, hipStream_t s, float* x0_out, const int64_t* slice_ids) {
     const int64_t total = (int64_t)B * HW;
     if (!total) return;
     const int blocks = (int)std::min<int64_t>((total + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(sampler_update_kernel, dim3(blocks), dim3(256), 0, s, sc, model_out, x, noise, seed, step, B, HW, x0_out);
+    hipLaunchKernelGGL(sampler_update_kernel, dim3(blocks), dim3(256), 0, s, sc, model_out, x, noise, seed, step, B, HW, x0_out, slice_ids);
     check_launch("sampler_update");
 }
 

@@ -53,11 +53,13 @@ def qkv_attention(qkv_ntc, heads, new_order=True):
     return a
 
 
-def timestep_embedding(t, dim):
+def timestep_embedding(t, dim, freqs=None):
+    """freqs: optional [dim//2] fp32 CUDA tensor, the caller's own exp(-ln(1e4) k / half) table (the shim path)."""
     is_float = t.dtype.is_floating_point
     t = t.float().contiguous() if is_float else t.long().contiguous()
     y = torch.empty((t.shape[0], dim), device=t.device, dtype=torch.float32)
-    check(lib().dsd_op_timestep_embedding(C.c_void_p(t.data_ptr()), int(is_float), t.shape[0], dim, dptr(y), stream_ptr()))
+    check(lib().dsd_op_timestep_embedding(C.c_void_p(t.data_ptr()), int(is_float), t.shape[0], dim, dptr(freqs), dptr(y),
+                                          stream_ptr()))
     return y
 
 

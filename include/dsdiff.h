@@ -71,7 +71,9 @@ void dsd_destroy(dsd_handle* h);
 int dsd_param_count(dsd_handle* h);
 int dsd_param_info(dsd_handle* h, int idx, const char** name, int64_t shape[4], int* ndim);
 /* Upload one parameter. src is fp32 in the reference layout; src_is_device selects the copy kind.
- * 3x3 conv weights are re-packed OIHW -> OHWI on device. */
+ * 3x3 conv weights are re-packed OIHW -> OHWI on device.  With src_is_device the copy is asynchronous on `stream`;
+ * later plan-time work of the library (splitting the weights into bf16 / fp16 pieces, on whatever stream the planning
+ * call is given) waits on an event recorded here, so uploads on a non-blocking stream need no extra synchronisation. */
 int dsd_set_param(dsd_handle* h, const char* name, const float* src, const int64_t* shape, int ndim,
                   int src_is_device, void* stream);
 /* Optional: the sinusoidal-embedding frequency table exp(-ln(1e4)*k/half), k < model_channels/2
@@ -106,6 +108,10 @@ int dsd_params_ready(dsd_handle* h);
  * never inside dsd_forward/dsd_sample once the plan for that shape exists. */
 int dsd_plan(dsd_handle* h, int B, int C, int H, int W);
 int64_t dsd_workspace_bytes(dsd_handle* h);
+/* Everything the handle holds on the device right now: parameter slab, upload staging, workspace arena, the bf16 / fp16
+ * weight pieces of the split arithmetic modes (6 B per convolution weight; only the family of the current mode is kept),
+ * sampling scratch. */
+int64_t dsd_device_bytes(dsd_handle* h);
 /* Number of kernel launches in the current plan's forward. */
 int dsd_plan_launches(dsd_handle* h);
 /* Algorithmic FLOPs (2*MAC of conv/linear/attention matmuls) of one forward of the current plan:
@@ -129,6 +135,17 @@ int dsd_profile_get(dsd_handle* h, int idx, const char** kind, double* total_ms,
                     int64_t* calls, int* runs);
 
 /* ---- sampling loop ----------------------------------------------------------------------- */
+/* Whole-forward hipGraph replay inside dsd_sample / dsd_sample_dpm (ON by default): the network evaluation of a step is
+ * a fixed list of ~1000 launches whose arguments do not change while the loop runs on the same buffers, so it is captured
+ * once (after the plan's first host-launched forward) and replayed per step; the reference's Python loop
+ * (gaussian_diffusion.py:569-616) pays the launches every step.  Results are bit-identical either way.  dsd_forward and
+ * dsd_profile_* always launch from the host. */
+int dsd_set_graph(dsd_handle* h, int on);
+int dsd_graph_stats(dsd_handle* h, int* captures, int* launches);
+/* Optional: the global slice index of every row of the next sampling batches (host array, n = batch size; n = 0 clears).
+ * With it the on-device Philox noise of a slice is keyed by (seed, step, slice index, pixel) instead of its position in
+ * the batch, so a volume gives the same samples however its slices are sharded over GPUs or grouped into batches. */
+int dsd_set_slice_ids(dsd_handle* h, const int64_t* ids_host, int n);
 enum { DSD_MODE_A_DDPM = 0, DSD_MODE_A_DDIM = 1, DSD_MODE_B_DDPM = 2, DSD_MODE_B_DDIM = 3 };
 enum { DSD_PRED_EPS = 0, DSD_PRED_X0 = 1, DSD_PRED_V = 2 };
 #define DSD_NCOEF 8
@@ -246,8 +263,10 @@ int dsd_op_group_norm(const float* x, int N, int HW, int C, const float* gamma, 
                       int silu, float* y, void* stream);
 /* QKVAttention / QKVAttentionLegacy (openaimodel.py:496-555) on qkv[N,T,3C] -> a[N,T,C]. */
 int dsd_op_qkv_attention(const float* qkv, int N, int T, int C, int heads, int new_order, float* a, void* stream);
-/* timestep_embedding (util.py:161-181): t[N] (int64 or fp32) -> [N,dim]. */
-int dsd_op_timestep_embedding(const void* t, int t_is_float, int N, int dim, float* y, void* stream);
+/* timestep_embedding (util.py:161-181): t[N] (int64 or fp32) -> [N,dim].  freqs (device, [dim/2], may be NULL): the
+ * frequency table as the caller's own fp32 exp evaluates it (what dsd_set_timestep_freqs installs in a model handle);
+ * with it the sin/cos arguments are bit-identical to the reference's. */
+int dsd_op_timestep_embedding(const void* t, int t_is_float, int N, int dim, const float* freqs, float* y, void* stream);
 /* y[N,O] = act_in(x[N,K]) @ w[O,K]^T + bias ; act_in: 0 none, 1 SiLU. */
 int dsd_op_linear(const float* x, int N, int K, const float* w, const float* bias, int O, int act_in, float* y,
                   void* stream);

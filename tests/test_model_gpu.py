@@ -263,6 +263,106 @@ def cond_image_(shape, seed):
     return cond_image(shape, seed)
 
 
+def test_full_size_vs_oracle(full_model):
+    """The BASELINE configuration AT ITS OWN SIZE against the CPU oracle (the headline kernels — 256-row tiles, NT = 5,
+    XCD-swizzled grids, batch-16 launch shapes — are never selected at 64x64):
+      (a) one 256x256 forward of the 981.5 M network, batch 1, vs the oracle: <= 1e-5 in bf16x6 (the default) and f32;
+      (c) the same slice as row 5 of a BATCH-16 forward (the launch shapes bench.py times, a different t per row): the
+          row must match the oracle's batch-1 result at the same tolerance;
+      (b) the last 3 steps of the 1000-step v-param DDPM chain at 256x256 with injected noise vs the oracle loop: <= 1e-4
+          on the fp32 image (north_star).
+    4 oracle forwards at 256x256 (~10 s each on the GPU box's host)."""
+    from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
+    from diffusion_models_dsdiff_amd._sched import run_device_loop
+    from oracle import samplers as OS
+    m, cfg, sd = full_model
+    row = 5
+    x16 = randn((16, 2, 256, 256), 81)
+    t16 = (torch.arange(16) * 61 + 7) % 1000
+    yo = O.unet_forward(cfg, sd, x16[row:row + 1], t16[row:row + 1])[0]
+    assert float(yo.abs().max()) > 1e-3
+    for prec in ("bf16x6", "f32"):
+        m.set_precision(prec)
+        y1 = m._run(x16[row:row + 1].cuda(), t16[row:row + 1].cuda(), want_feats=False)[0]
+        e1 = rel_l2(y1, yo)
+        y16 = m._run(x16.cuda(), t16.cuda(), want_feats=False)[0]
+        e16 = rel_l2(y16[row:row + 1], yo)
+        print(f"full-size forward 256x256 {prec}: batch-1 rel-L2 {e1:.3e}, row {row} of batch 16 rel-L2 {e16:.3e}")
+        assert e1 < 1e-5 and e16 < 1e-5, prec
+        assert bool(torch.isfinite(y16).all())
+    m.set_precision("bf16x6")
+    # (b) last 3 steps of the chain
+    shape, n = (1, 1, 256, 256), 3
+    cond, x_start = cond_image_(shape, 82), randn(shape, 83)
+    z = torch.zeros((1000,) + shape)
+    z[1000 - n:] = randn((n,) + shape, 84)
+    d = create_gaussian_diffusion(steps=1000, parameterization="v")
+    sched = d._schedule(False, 0.0, True)
+    y = run_device_loop(m, sched, x_start.cuda(), cond.cuda(), step_noise=z.cuda(), first_step=1000 - n, n_steps=n)
+    od = OS.DiffusionA(steps=1000, parameterization="v")
+    model = lambda xx, tt: O.unet_forward(cfg, sd, xx, tt)[0]
+    img = x_start
+    for k in range(1000 - n, 1000):
+        t = torch.tensor([999 - k])
+        mean, log_var, _ = od.p_mean_variance(model, img, t, True, [cond])
+        img = mean + (t != 0).float().view(-1, 1, 1, 1) * torch.exp(0.5 * log_var) * z[k]
+    err = rel_l2(y, img)
+    print(f"full-size last-{n}-steps DDPM chain 256x256 bf16x6: rel-L2 {err:.3e}")
+    assert err < 1e-4
+
+
+def test_full_size_graph_replay_is_bit_identical(full_model):
+    """dsd_sample replays ONE captured hipGraph per denoising step (include/dsdiff.h: dsd_set_graph): the result must be
+    bit-identical to launching every kernel from the host, at the headline size and at batch 1 and 2."""
+    from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
+    from diffusion_models_dsdiff_amd._sched import run_device_loop
+    m, _, _ = full_model
+    d = create_gaussian_diffusion(steps=1000, parameterization="v")
+    sched = d._schedule(False, 0.0, True)
+    for B in (1, 2):
+        shape = (B, 1, 256, 256)
+        cond, xT = cond_image_(shape, 91).cuda(), randn(shape, 92).cuda()
+        m.use_graph(False)
+        a = run_device_loop(m, sched, xT, cond, seed=9, first_step=0, n_steps=4)
+        m.use_graph(True)
+        before = m.graph_stats()
+        b = run_device_loop(m, sched, xT, cond, seed=9, first_step=0, n_steps=4)
+        after = m.graph_stats()
+        assert torch.equal(a, b)
+        assert after["launches"] - before["launches"] >= 3, (before, after)     # the graph really ran
+    m.use_graph(True)
+
+
+def test_data_edits_are_uploaded():
+    """ADVICE r1: edits through ``p.data`` (LitEma.copy_to / ema_scope swap idiom) bump neither _version nor data_ptr;
+    the value fingerprint of sync_params must catch them, and mark_dirty() / force=True must always work."""
+    g, m, params = tiny_native("tiny")
+    cfg, sd = O.UNetConfig.from_params(params), fixture_params(g, "tiny")
+    x, t = randn((2, 4, 32, 32), 71), torch.tensor([999, 17])
+    y0, _ = m(x.cuda(), t.cuda())
+    assert rel_l2(y0, O.unet_forward(cfg, sd, x, t)[0]) < TOL_MODEL
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    gen = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        for k in ("out.2.weight", "middle_block.0.in_layers.2.weight", "input_blocks.1.0.emb_layers.1.bias"):
+            sd2[k] = torch.randn(sd2[k].shape, generator=gen) * 0.05
+            p = dict(m.named_parameters())[k]
+            v0, ptr0 = p._version, p.data_ptr()
+            p.data.copy_(sd2[k])                                   # the idiom that defeats version tracking
+            assert p._version == v0 and p.data_ptr() == ptr0
+    y1, _ = m(x.cuda(), t.cuda())
+    want = O.unet_forward(cfg, sd2, x, t)[0]
+    assert rel_l2(y1, want) < TOL_MODEL and rel_l2(y1, y0) > 1e-3
+    # an edit the three probed elements cannot see needs the explicit route
+    with torch.no_grad():
+        p = dict(m.named_parameters())["out.2.weight"]
+        p.data.view(-1)[1] += 0.5
+        sd2["out.2.weight"] = p.detach().clone()
+    m.mark_dirty(["out.2.weight"])
+    y2, _ = m(x.cuda(), t.cuda())
+    assert rel_l2(y2, O.unet_forward(cfg, sd2, x, t)[0]) < TOL_MODEL
+
+
 def test_full_size_properties(full_model):
     """BASELINE size (256x256, the 981.5 M network) is far beyond what the CPU oracle can check in a test (~10 s per
     forward, 2.8 h per sample), so it is covered by size-independent properties on 3 denoising steps of the DDPM chain:

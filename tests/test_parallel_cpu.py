@@ -75,3 +75,34 @@ def test_single_process_is_identity():
     assert parallel.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
     x = torch.arange(6.).reshape(3, 2)
     assert parallel.gather_slices(x, 3) is x
+
+
+def test_bench_self_launch_two_ranks_gloo():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment must start the two ranks ITSELF (the driver's
+    call form), rendezvous, take the max over ranks, gather, and print ONE line with n_gpus = 2.  Rehearsed on the CPU:
+    gloo backend + the stubbed compute leg (rank r sleeps 2(r+1) ms per step, so the max-over-ranks is rank 1's)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(DSD_BENCH_BACKEND="gloo", DSD_BENCH_STUB="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["steps"] == 5 and out["scaling"] == "weak"
+    assert len(out["per_rank_ms_per_step"]) == 2
+    # the timed region is bracketed by barriers, so every rank's clock covers the slowest rank (4 ms per step, rank 1)
+    assert out["ms_per_step"] == max(out["per_rank_ms_per_step"]) and min(out["per_rank_ms_per_step"]) >= 4.0
+    assert out["gather_ms"] is not None and out["extra"]["weight_broadcast_ms"] is not None
+    assert out["extra"]["launched_by"].startswith("self")
+    # whole-job value: slices of ALL ranks / time
+    assert abs(out["value"] - 2 * 16 / (1000.0 * out["ms_per_step"] / 1e3)) < 1e-3 * out["value"]
+    assert out["metric"] is None and out["valid_for_baseline"] is False and "STUB" in out["data"]
+
+
+def test_bench_rejects_gpus_world_mismatch():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", DSD_BENCH_STUB="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=120, cwd=ROOT)
+    assert r.returncode != 0 and "one rank per GPU" in r.stderr

@@ -227,3 +227,57 @@ def test_baseline_config_0_and_2_shapes(env):
     with pytest.raises((_lib.DsdError, AssertionError, RuntimeError)):
         d.ddim_sample_loop(fm, (1, 1, 30, 30), noise=torch.zeros(1, 1, 30, 30).cuda(), clip_denoised=True,
                            model_kwargs=dict(c_concat=[torch.zeros(1, 3, 30, 30).cuda()]), eta=0.0)
+
+
+def test_philox_noise_is_keyed_by_slice_not_by_batch_position(env):
+    """with dsd_set_slice_ids the on-device noise of a slice depends on (seed, step, slice index) only, so a
+    volume sampled as one batch, as two shards ([r::2], what 2 ranks do) or slice by slice gives the same images."""
+    from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
+    gl, wrap, _, _, _ = env
+    unet = wrap.diffusion_model
+    n = 5
+    shape = (n, 1, 32, 32)
+    cond, xT = cond_image(shape, 700).cuda(), randn(shape, 701).cuda()
+    d = create_gaussian_diffusion(steps=1000, timestep_respacing="10", rescale_timesteps=True, parameterization="v")
+
+    def run(idx):
+        idx = list(idx)
+        unet.set_slice_ids(idx)
+        y = d.p_sample_loop(wrap, (len(idx), 1, 32, 32), noise=xT[idx], clip_denoised=True,
+                            model_kwargs=dict(c_concat=[cond[idx]]), seed=1234)
+        unet.set_slice_ids(None)
+        return y
+    whole = run(range(n))
+    for r in range(2):                                       # the [r::R] shards of parallel.shard_indices
+        idx = list(range(r, n, 2))
+        part = run(idx)
+        assert rel_l2(part, whole[idx]) < 1e-6               # kernels may tile a smaller batch differently: fp32 rounding
+    single = run([3])
+    assert rel_l2(single, whole[3:4]) < 1e-6
+    # without ids the noise follows the batch position (the old behaviour): slice 3 alone then differs from slice 3 in the batch
+    y = d.p_sample_loop(wrap, (1, 1, 32, 32), noise=xT[3:4], clip_denoised=True, model_kwargs=dict(c_concat=[cond[3:4]]), seed=1234)
+    assert rel_l2(y, whole[3:4]) > 1e-3
+    with pytest.raises(Exception):                           # ids must match the batch
+        unet.set_slice_ids([0, 1])
+        d.p_sample_loop(wrap, (n, 1, 32, 32), noise=xT, clip_denoised=True, model_kwargs=dict(c_concat=[cond]), seed=1)
+    unet.set_slice_ids(None)
+
+
+def test_graph_replay_matches_host_launches(env):
+    """hipGraph replay of the network evaluation inside dsd_sample / dsd_sample_dpm is bit-identical to host launches."""
+    from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
+    gl, wrap, cond, xT, _ = env
+    unet = wrap.diffusion_model
+    d = create_gaussian_diffusion(steps=1000, timestep_respacing="20", rescale_timesteps=True, parameterization="v")
+    kw = dict(noise=xT, clip_denoised=True, model_kwargs=dict(c_concat=[cond]))
+    out = {}
+    for on in (False, True):
+        unet.use_graph(on)
+        s0 = unet.graph_stats()
+        out[on] = (d.p_sample_loop(wrap, SHAPE, seed=5, **kw), d.ddim_sample_loop(wrap, SHAPE, eta=0.5, seed=6, **kw),
+                   d.dpm_solver_sample_loop(wrap, SHAPE, model_kwargs=dict(c_concat=[cond]), noise=xT))
+        s1 = unet.graph_stats()
+        assert (s1["launches"] > s0["launches"]) == on
+    unet.use_graph(True)
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a, b)

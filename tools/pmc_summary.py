@@ -12,6 +12,11 @@ import json
 import sys
 
 fetch_dir, write_dir, sq_dir, out = sys.argv[1:5]
+# provenance (bench.py prints it beside roofline.traffic): precision, the git HEAD the library was built from (passed in by
+# the caller — the GPU box has no .git) and the profiled command
+meta = {"precision": sys.argv[5] if len(sys.argv) > 5 else "bf16x6", "git_head": sys.argv[6] if len(sys.argv) > 6 else None,
+        "command": sys.argv[7] if len(sys.argv) > 7 else None,
+        "method": "rocprofv3 --kernel-trace --pmc, one pass per counter group; FETCH_SIZE x2 (gfx950), KiB -> bytes"}
 
 
 def load(path):
@@ -57,5 +62,6 @@ for k in sorted(fe, key=lambda k: -sum(du.get(k, [0]))):
     if s.get("SQ_LDS_IDX_ACTIVE"):
         e["lds_bank_conflict_frac"] = round(s.get("SQ_LDS_BANK_CONFLICT", 0) / s["SQ_LDS_IDX_ACTIVE"], 4)
     res[k.replace("void ", "")[:60]] = e
+res["_meta"] = meta
 json.dump(res, open(out + ".json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])

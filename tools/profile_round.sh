@@ -1,6 +1,7 @@
 #!/bin/bash
 # rocprofv3 evidence for profiles/: kernel trace + three PMC passes of the SAME bench command (GPU box).
-#   tools/profile_round.sh r01 [precision]        -> profiles/<tag>_kernel_stats.{txt,json}, profiles/<tag>_pmc[_prec].json
+#   GIT_HEAD=<sha> tools/profile_round.sh r02 [precision]  -> profiles/<tag>_kernel_stats.{txt,json}, profiles/<tag>_pmc[_prec].json
+# (copied to gpurun_out/profiles/ so they come back from the GPU box; GIT_HEAD is recorded as provenance)
 # Counters are collected in their own runs (--kernel-trace + --pmc only), as the pool requires.
 set -e
 TAG=${1:-r01}
@@ -18,5 +19,6 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES S
 cd $R
 DB=$(ls $O/prof_$TAG$SUF/*/*.db $O/prof_$TAG$SUF/*.db 2>/dev/null | head -1)
 python3 tools/rocprof_summary.py "$DB" profiles/${TAG}_kernel_stats$SUF
-python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq profiles/${TAG}_pmc$SUF
+python3 tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O/pmc_sq profiles/${TAG}_pmc$SUF "$PREC" "${GIT_HEAD:-unknown}" "${B#python3 $R/}"
+mkdir -p $O/profiles && cp profiles/${TAG}_* $O/profiles/
 tail -1 $O/prof_$TAG$SUF.log
