@@ -91,6 +91,11 @@ class NativeModule(nn.Module):
         check(lib().dsd_set_graph(self._h, int(on)))
         return self
 
+    def fuse_gn_stats(self, on: bool = True):
+        """GroupNorm statistics from the producing kernel's epilogue (default) or from the standalone pass."""
+        check(lib().dsd_set_fuse_gn_stats(self._h, int(on)))
+        return self
+
     def graph_stats(self):
         c, l = C.c_int(), C.c_int()
         check(lib().dsd_graph_stats(self._h, C.byref(c), C.byref(l)))

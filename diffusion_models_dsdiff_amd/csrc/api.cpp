@@ -233,6 +233,16 @@ int dsd_set_graph(dsd_handle* h, int on) {
     DSD_CATCH
 }
 
+int dsd_set_fuse_gn_stats(dsd_handle* h, int on) {
+    DSD_TRY
+    DSD_CHECK(h, "null handle");
+    if (h->fuse_gn_stats != (on != 0)) {
+        h->fuse_gn_stats = on != 0;
+        h->plan.valid = false;
+    }
+    DSD_CATCH
+}
+
 int dsd_graph_stats(dsd_handle* h, int* captures, int* launches) {
     DSD_TRY
     DSD_CHECK(h, "null handle");
@@ -591,9 +601,11 @@ int dsd_op_group_norm(const float* x, int N, int HW, int C, const float* gamma, 
     DSD_TRY
     hipStream_t s = (hipStream_t)stream;
     const int nchunk = gn_nchunks(HW, C);
-    Tmp part((size_t)N * nchunk * 32 * 2 * sizeof(double)), sc((size_t)N * C * sizeof(float)), sh((size_t)N * C * sizeof(float));
+    Tmp part((size_t)N * nchunk * C * 2 * sizeof(double)), sc((size_t)N * C * sizeof(float)), sh((size_t)N * C * sizeof(float));
     gn_stats(x, N, HW, C, part.as<double>(), nchunk, s);
-    gn_finalize(part.as<double>(), nchunk, N, HW, C, gamma, beta, eps, nullptr, 0, sc.as<float>(), sh.as<float>(), s);
+    GnSrc s0;
+    s0.p = part.as<double>(); s0.chunks = nchunk; s0.c0 = 0; s0.c = C;
+    gn_finalize(s0, GnSrc{}, N, HW, C, gamma, beta, eps, nullptr, 0, sc.as<float>(), sh.as<float>(), s);
     affine_act(x, N, HW, C, sc.as<float>(), sh.as<float>(), silu ? ACT_SILU : ACT_NONE, y, s);
     DSD_HIP(hipStreamSynchronize(s));
     DSD_CATCH

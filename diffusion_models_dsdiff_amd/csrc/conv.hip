@@ -623,6 +623,24 @@ size_t conv2d_scratch_bytes(const ConvArgs& a) {
     return ks > 1 ? (size_t)ks * M * a.Cout * sizeof(float) : 0;
 }
 
+int conv2d_stats_chunks(const ConvArgs& a) {
+    // only the split-precision implicit-GEMM kernels carry the statistics epilogue (and not their split-K form, whose
+    // output is written by the reduction kernel)
+    if (a.out_nchw || a.Cin % 4 != 0 || a.ks * a.ks * a.Cin < 32) return 0;
+    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
+    const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
+    const int64_t M = (int64_t)a.N * OH * OW;
+    const int tm = cdiv(M, BM);
+    const int pr = effective_precision(a, tm);
+    if (pr == PREC_F32) return 0;
+    int nt = pick_nt(a.Cout, tm, pr), ks = 1, ad = 0;
+    conv2d_split_plan(a, nt, &nt, &ks, &ad);
+    if (ks > 1) return 0;
+    const int rows = ad == 2 ? 2 * BM : BM;
+    const int ohw = OH * OW;
+    return ohw % rows == 0 ? ohw / rows : 0;
+}
+
 void conv2d_plan_query(const ConvArgs& a, int* structure, int* nt_out, int* ks_out) {
     const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
     const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;

@@ -58,6 +58,8 @@ struct SplitP {
     int y_ld;         // row stride of y (>= Cout)
     int ksplit;       // split-K: the k-tiles are divided over ksplit workgroups per output tile (A-direct 128-row kernel)
     float* partial;   // [ksplit][M][Cout] raw partial sums, reduced (+ bias / embedding / residual) by splitk_reduce_kernel
+    double* stats;    // GroupNorm statistics of the output, [sample][chunk][Cout][2] (GnSrc layout), or nullptr
+    int stats_chunks; // chunks per sample = ohw / block-tile rows (a block tile never straddles two samples then)
 };
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -113,9 +115,13 @@ __device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NP], int* ovf = nul
 }
 
 // ---- accumulators -> memory: bias + per-(sample,channel) embedding + residual (same fusion as the fp32 kernel)
-template <int NT>
+// STATS: every stored value is also added (fp32, this lane's 16 rows of its NT columns) into cs / cq = sum / sum of squares
+// of the column: the GroupNorm statistics of the tensor being written, reduced further by stats_reduce below.  Rounding
+// of the 16-to-32-term fp32 partials is unbiased and is averaged over the >= 60 partials of a group (sum beyond that is
+// fp64), so the statistics stay at fp64 quality for the purposes of the 2e-6 GroupNorm tolerance.
+template <int NT, bool STATS = false>
 __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&acc)[NT], int m0, int n0, int wave, int lrow,
-                                               int half, int tile_rows = SBM) {
+                                               int half, int tile_rows, float (&cs)[NT], float (&cq)[NT]) {
     constexpr int BROWS = NT * 32;
     const bool interior = (m0 + tile_rows <= p.M) && (n0 + BROWS <= p.Cout) && !p.out_nchw;
     if (interior) {
@@ -151,6 +157,10 @@ __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&a
                     if (p.emb) v += ev[rr][j];
                     if (p.res) v += rv[rr][j];
                     yp[j * 32] = v;
+                    if (STATS) {
+                        cs[j] += v;
+                        cq[j] = fmaf(v, v, cq[j]);
+                    }
                 }
             }
         }
@@ -169,11 +179,59 @@ __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&a
             if (p.bias) v += p.bias[n];
             if (p.emb) v += p.emb[(int64_t)nb * p.emb_stride + n];
             if (p.res) v += p.res[(int64_t)m * p.Cout + n];
+            if (STATS) {
+                cs[j] += v;
+                cq[j] = fmaf(v, v, cq[j]);
+            }
             if (p.out_nchw)
                 p.y[((int64_t)nb * p.Cout + n) * p.ohw + (m - nb * p.ohw)] = v;
             else
                 p.y[(int64_t)m * p.y_ld + n] = v;
         }
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&acc)[NT], int m0, int n0, int wave, int lrow,
+                                               int half, int tile_rows = SBM) {
+    float cs[NT], cq[NT];
+    split_epilogue<NT, false>(p, acc, m0, n0, wave, lrow, half, tile_rows, cs, cq);
+}
+
+// Column sums of one block tile -> p.stats.  Lanes l and l+32 hold the two row halves of a column, the four waves the row
+// blocks: combined through the (now idle) LDS in a fixed order, so the result is deterministic.  One (sum, sumsq) pair per
+// column and block tile; the tile lies inside one sample (host guarantees ohw % tile rows == 0).
+template <int NT>
+__device__ __forceinline__ void stats_reduce(const SplitP& p, const float (&cs)[NT], const float (&cq)[NT], unsigned char* lds,
+                                             int m0, int n0, int tile_rows, int tid, int wave, int lrow, int half) {
+    constexpr int BROWS = NT * 32;
+    double* red = reinterpret_cast<double*>(lds);   // [4 waves][BROWS][2]
+    __syncthreads();                                 // every wave is done with the operand tiles in LDS
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        double s = (double)cs[j], q = (double)cq[j];
+        s += __shfl_xor(s, 32);
+        q += __shfl_xor(q, 32);
+        if (half == 0) {
+            red[((wave * BROWS) + j * 32 + lrow) * 2 + 0] = s;
+            red[((wave * BROWS) + j * 32 + lrow) * 2 + 1] = q;
+        }
+    }
+    __syncthreads();
+    const int nb = m0 / p.ohw;
+    const int chunk = (m0 - nb * p.ohw) / tile_rows;
+    for (int c = tid; c < BROWS; c += 256) {
+        const int n = n0 + c;
+        if (n >= p.Cout) continue;
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            s += red[((w * BROWS) + c) * 2 + 0];
+            q += red[((w * BROWS) + c) * 2 + 1];
+        }
+        double* o = p.stats + (((int64_t)nb * p.stats_chunks + chunk) * p.Cout + n) * 2;
+        o[0] = s;
+        o[1] = q;
     }
 }
 
@@ -350,6 +408,14 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
         kstep(1);
     }
 
+    if (p.stats) {
+        float cs[NT], cq[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) cs[j] = cq[j] = 0.f;
+        split_epilogue<NT, true>(p, acc, m0, n0, wave, lrow, half, SBM, cs, cq);
+        stats_reduce<NT>(p, cs, cq, lds, m0, n0, SBM, tid, wave, lrow, half);
+        return;
+    }
     split_epilogue<NT>(p, acc, m0, n0, wave, lrow, half);
 }
 
@@ -631,6 +697,15 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         for (int r = 0; r < RB; ++r) split_epilogue<NT>(q, acc[r], m0, n0, wave * RB + r, lrow, half, SBM * RB);
         return;
     }
+    if (p.stats) {
+        float cs[NT], cq[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) cs[j] = cq[j] = 0.f;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) split_epilogue<NT, true>(p, acc[r], m0, n0, wave * RB + r, lrow, half, SBM * RB, cs, cq);
+        stats_reduce<NT>(p, cs, cq, Bs, m0, n0, SBM * RB, tid, wave, lrow, half);
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < RB; ++r) split_epilogue<NT>(p, acc[r], m0, n0, wave * RB + r, lrow, half, SBM * RB);
 }
@@ -831,6 +906,16 @@ void conv2d_split(const ConvArgs& a, int nt, int ksplit, int ad, hipStream_t s) 
                   (size_t)ksplit * p.M * a.Cout * sizeof(float), a.scratch_bytes);
         p.ksplit = ksplit;
         p.partial = a.scratch;
+    }
+    p.stats = nullptr;
+    p.stats_chunks = 0;
+    if (a.stats) {
+        const int rows = ad == 2 ? 2 * SBM : SBM;
+        DSD_CHECK(p.ksplit == 1 && !a.out_nchw && p.ohw % rows == 0 && p.ohw / rows == a.stats_chunks,
+                  "conv2d: output statistics requested with %d chunks but the kernel (tile %d rows, split-K x%d, ohw %d) cannot "
+                  "emit them (conv2d_stats_chunks)", a.stats_chunks, rows, p.ksplit, p.ohw);
+        p.stats = a.stats;
+        p.stats_chunks = a.stats_chunks;
     }
     if (a.precision == PREC_F16X3)
         launch_split<2, true>(p, nt, s, ad);

@@ -28,7 +28,14 @@ struct ConvArgs {
     int* ovf = nullptr;             // device flag set by the f16x3 kernels when an operand exceeds the fp16 range
     float* scratch = nullptr;       // split-K partial sums (conv2d_scratch_bytes() bytes); without it small grids run unsplit
     size_t scratch_bytes = 0;
+    // GroupNorm statistics of the OUTPUT, accumulated in the epilogue: stats[n][chunk][co][2] doubles (GnSrc layout),
+    // stats_chunks = conv2d_stats_chunks() chunks per sample; nullptr = not wanted
+    double* stats = nullptr;
+    int stats_chunks = 0;
 };
+// chunks per sample the kernel conv2d() will launch for these arguments can emit output statistics with (0 = it cannot:
+// the caller runs gn_stats on the output instead)
+int conv2d_stats_chunks(const ConvArgs& a);
 enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16X6 = 2, PREC_F16X3 = 3 };
 void conv2d(ConvArgs a, hipStream_t s);
 // conv_split.hip: fp32 operands as sums of bf16 pieces on the bf16 matrix cores
@@ -46,12 +53,22 @@ void pack_ohwi(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, hi
 
 // ---------------------------------------------------------------- norm.hip
 int gn_nchunks(int HW, int C);
-// partial: [N][nchunk][32][2] doubles (sum, sumsq)
+// Per-column statistics of the channels [c0, c0+c) of a tensor: p[n][chunk][col][2] doubles (sum, sumsq over the chunk's
+// pixels), `chunks` chunks per sample.  Written by gn_stats, by avg_into_stats and by the convolution epilogues.
+struct GnSrc {
+    const double* p = nullptr;
+    int chunks = 0, c0 = 0, c = 0;
+};
+// partial: [N][nchunk][C][2] doubles
 void gn_stats(const float* x, int N, int HW, int C, double* partial, int nchunk, hipStream_t s);
 // scale/shift: [N][C] so that GN(x) = x*scale + shift; film (optional, [N][film_stride] = scale|shift halves):
-// (GN(x))*(1+fs)+fsh folded in (ResBlock use_scale_shift_norm, openaimodel.py:276-280)
-void gn_finalize(const double* partial, int nchunk, int N, int HW, int C, const float* gamma, const float* beta,
+// (GN(x))*(1+fs)+fsh folded in (ResBlock use_scale_shift_norm, openaimodel.py:276-280).  s0 covers channels [0, s0.c),
+// s1 (optional: p == nullptr) the rest — a concatenated tensor has one source per part.
+void gn_finalize(const GnSrc& s0, const GnSrc& s1, int N, int HW, int C, const float* gamma, const float* beta,
                  float eps, const float* film, int film_stride, float* scale, float* shift, hipStream_t s);
+// avg_into (misc.hip) on [N][HW][C] sources + the per-column statistics of what it wrote: partial [N][gn_nchunks(HW,C)][C][2]
+void avg_into_stats(const float* a, const float* b, const float* c, const float* d, float div, int N, int HW, int C,
+                    float* dst, int dstC, int coff, int act, int bmask, double* partial, int nchunk, hipStream_t s);
 enum { ACT_NONE = 0, ACT_SILU = 1 };
 void affine_act(const float* x, int N, int HW, int C, const float* scale, const float* shift, int act, float* y,
                 hipStream_t s);

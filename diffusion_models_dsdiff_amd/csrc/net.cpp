@@ -473,6 +473,10 @@ struct Builder {
     void release(Tn& t) {
         if (t.valid()) ar.release(t.off, t.bytes());
         t.off = (size_t)-1;
+        for (auto& st : t.st) {   // the statistics that travelled with the tensor die with it
+            if (st.valid()) ar.release(st.off, st.bytes(t.n));
+            st = StatRef{};
+        }
     }
     size_t alloc_raw(size_t bytes) { return ar.alloc(bytes); }
     void release_raw(size_t off, size_t bytes) { ar.release(off, bytes); }
@@ -499,7 +503,7 @@ struct Builder {
     // of a tensor of its own — the decoder's cat([h, skip]) without the copy of h; the returned Tn is then a view of *dst.
     Tn conv(const std::string& name, const Tn& x, int cout, int ks, int stride = 1, bool ups = false,
             const EmbRef* emb = nullptr, const Tn* res = nullptr, int plane = -1, bool to_out = false, bool bias = true,
-            const Tn* dst = nullptr) {
+            const Tn* dst = nullptr, bool want_stats = false) {
         ConvArgs a;
         a.N = x.n; a.H = x.h; a.W = x.w; a.Cin = x.c; a.Cout = cout; a.ks = ks; a.stride = stride; a.ups = ups ? 1 : 0;
         a.w = W(name + ".weight");
@@ -515,6 +519,7 @@ struct Builder {
                       "conv %s: destination view does not fit", name.c_str());
             y = *dst;
             y.c = cout;
+            y.st[0] = y.st[1] = StatRef{};
         } else if (!to_out) {
             y = alloc(x.n, OH, OW, cout);
         }
@@ -543,6 +548,20 @@ struct Builder {
         }
         const size_t skb = conv2d_scratch_bytes(a);            // split-K partial tiles of the small-grid layers
         const size_t skoff = skb ? alloc_raw(skb) : 0;
+        // GroupNorm statistics of the output from the epilogue, when the kernel this problem gets can emit them
+        size_t stoff = 0;
+        int stchunks = 0;
+        if (want_stats && !to_out && hd->fuse_gn_stats) {
+            ConvArgs q = a;
+            q.x_bs = -1;
+            stchunks = conv2d_stats_chunks(q);
+            if (stchunks > 0) {
+                StatRef sr;
+                sr.chunks = stchunks; sr.c0 = 0; sr.c = cout;
+                sr.off = stoff = alloc_raw(sr.bytes(x.n));
+                y.st[0] = sr;
+            }
+        }
         const size_t xoff = x.off, yoff = y.off, roff = res ? res->off : 0;
         const bool has_res = res != nullptr;
         EmbRef e;
@@ -571,6 +590,10 @@ struct Builder {
                 c.scratch = reinterpret_cast<float*>(h->arena + skoff);
                 c.scratch_bytes = skb;
             }
+            if (stchunks > 0) {
+                c.stats = reinterpret_cast<double*>(h->arena + stoff);
+                c.stats_chunks = stchunks;
+            }
             conv2d(c, s);
         }, skb ? 2 : 1, conv2d_variant(a), conv2d_flops(a),
            4.0 * ((double)x.n * x.h * x.w * x.c + (double)cout * x.c * ks * ks + (double)x.n * OH * OW * cout * (has_res ? 2 : 1)));
@@ -581,10 +604,14 @@ struct Builder {
     // ---- GroupNorm32 (+SiLU, + FiLM) : stats, finalize, apply
     Tn gn_act(const std::string& name, const Tn& x, int act, float eps = 1e-5f, const EmbRef* film = nullptr) {
         const int HW = x.hw(), C = x.c, N = x.n;
+        // statistics that came with the tensor (convolution epilogue / concat kernel), else a pass of our own
+        const bool have = x.st[0].valid() && x.st[0].c0 == 0 &&
+                          (x.st[0].c == C || (x.st[1].valid() && x.st[1].c0 == x.st[0].c && x.st[0].c + x.st[1].c == C));
+        const StatRef r0 = x.st[0], r1 = (have && x.st[0].c < C) ? x.st[1] : StatRef{};
         const int nchunk = gn_nchunks(HW, C);
-        const size_t pbytes = (size_t)N * nchunk * 32 * 2 * sizeof(double);
+        const size_t pbytes = have ? 0 : (size_t)N * nchunk * C * 2 * sizeof(double);
         const size_t sbytes = (size_t)N * C * sizeof(float);
-        const size_t poff = alloc_raw(pbytes), scoff = alloc_raw(sbytes), shoff = alloc_raw(sbytes);
+        const size_t poff = have ? 0 : alloc_raw(pbytes), scoff = alloc_raw(sbytes), shoff = alloc_raw(sbytes);
         Tn y = alloc(x.n, x.h, x.w, x.c);
         const float* gamma = W(name + ".weight");
         const float* beta = W(name + ".bias");
@@ -595,19 +622,29 @@ struct Builder {
         if (film) e = *film;
         dsd_handle* h = hd;
         const double tbytes = 4.0 * N * HW * C;
-        op([=](hipStream_t s) {
-            gn_stats(reinterpret_cast<const float*>(h->arena + xoff), N, HW, C, reinterpret_cast<double*>(h->arena + poff), nchunk, s);
-        }, 1, "gn_stats", 0.0, tbytes);
+        if (!have)
+            op([=](hipStream_t s) {
+                gn_stats(reinterpret_cast<const float*>(h->arena + xoff), N, HW, C, reinterpret_cast<double*>(h->arena + poff), nchunk, s);
+            }, 1, "gn_stats", 0.0, tbytes);
         op([=](hipStream_t s) {
             const float* fp = e.valid ? reinterpret_cast<const float*>(h->arena + e.arena_off) + e.col : nullptr;
-            gn_finalize(reinterpret_cast<double*>(h->arena + poff), nchunk, N, HW, C, gamma, beta, eps, fp, e.stride,
+            GnSrc s0, s1;
+            if (have) {
+                s0.p = reinterpret_cast<const double*>(h->arena + r0.off); s0.chunks = r0.chunks; s0.c0 = 0; s0.c = r0.c;
+                if (r1.valid()) {
+                    s1.p = reinterpret_cast<const double*>(h->arena + r1.off); s1.chunks = r1.chunks; s1.c0 = r1.c0; s1.c = r1.c;
+                }
+            } else {
+                s0.p = reinterpret_cast<const double*>(h->arena + poff); s0.chunks = nchunk; s0.c0 = 0; s0.c = C;
+            }
+            gn_finalize(s0, s1, N, HW, C, gamma, beta, eps, fp, e.stride,
                         reinterpret_cast<float*>(h->arena + scoff), reinterpret_cast<float*>(h->arena + shoff), s);
         }, 1, "gn_finalize");
         op([=](hipStream_t s) {
             affine_act(reinterpret_cast<const float*>(h->arena + xoff), N, HW, C, reinterpret_cast<float*>(h->arena + scoff),
                        reinterpret_cast<float*>(h->arena + shoff), act, reinterpret_cast<float*>(h->arena + yoff), s);
         }, 1, act == ACT_SILU ? "gn_silu_apply" : "gn_apply", 0.0, 2.0 * tbytes);
-        release_raw(poff, pbytes);
+        if (!have) release_raw(poff, pbytes);
         release_raw(scoff, sbytes);
         release_raw(shoff, sbytes);
         return y;
@@ -641,7 +678,8 @@ struct Builder {
             xs = resample(x, up);
             xs_owned = true;
         }
-        Tn h = conv(pre(p, "in_layers.2"), a, cout, 3, 1, false, film ? nullptr : &emb);
+        Tn h = conv(pre(p, "in_layers.2"), a, cout, 3, 1, false, film ? nullptr : &emb, nullptr, -1, false, true, nullptr,
+                    /*want_stats=*/true);   // out_layers.0 normalises exactly this tensor
         release(a);
         Tn a3 = gn_act(pre(p, "out_layers.0"), h, ACT_SILU, 1e-5f, film ? &emb : nullptr);
         release(h);
@@ -651,7 +689,7 @@ struct Builder {
             skip = conv(pre(p, "skip_connection"), xs, cout, 1);
             skip_owned = true;
         }
-        Tn out = conv(pre(p, "out_layers.3"), a3, cout, 3, 1, false, nullptr, &skip, -1, false, true, dst);
+        Tn out = conv(pre(p, "out_layers.3"), a3, cout, 3, 1, false, nullptr, &skip, -1, false, true, dst, true);
         release(a3);
         if (skip_owned) release(skip);
         if (xs_owned) release(xs);
@@ -693,7 +731,7 @@ struct Builder {
             }, 1, "attention", 4.0 * x.n * heads * (double)T * T * d);
         }
         release(qkv);
-        Tn out = conv(pre(p, "proj_out"), a, C, 1, 1, false, nullptr, &x, -1, false, true, dst);
+        Tn out = conv(pre(p, "proj_out"), a, C, 1, 1, false, nullptr, &x, -1, false, true, dst, true);
         release(a);
         return out;
     }
@@ -701,7 +739,7 @@ struct Builder {
     // FeatureDisentangle.forward, model.py:165-168
     Tn disentangle(const std::string& p, const Tn& x, int half) {
         Tn a = gn_act(pre(p, "conv_1.0"), x, ACT_SILU);
-        Tn o = conv(pre(p, "conv_1.2"), a, x.c, 3, 1, false, nullptr, &x);
+        Tn o = conv(pre(p, "conv_1.2"), a, x.c, 3, 1, false, nullptr, &x, -1, false, true, nullptr, true);
         release(a);
         Tn a2 = gn_act(pre(p, "conv_2.0"), o, ACT_SILU);
         release(o);
@@ -726,7 +764,8 @@ struct Builder {
     }
 
     // dst[:, coff:coff+C] = act((a+b+c+d)/div)
-    void avg(const Tn* srcs, int nsrc, float div, const Tn& dst, int coff, int act) {
+    // want_stats: also emit the GroupNorm statistics of the written channels (they become dst.st[coff ? 1 : 0])
+    void avg(const Tn* srcs, int nsrc, float div, Tn& dst, int coff, int act, bool want_stats = false) {
         size_t o[4] = {0, 0, 0, 0};
         int bmask = 0;
         for (int i = 0; i < nsrc; ++i) {
@@ -740,6 +779,21 @@ struct Builder {
         const size_t doff = dst.off;
         const int dstC = dst.c;
         dsd_handle* h = hd;
+        if (want_stats && hd->fuse_gn_stats && C % 32 == 0 && (coff == 0 || dst.st[0].valid())) {
+            StatRef sr;
+            sr.chunks = gn_nchunks((int)per_sample, C); sr.c0 = coff; sr.c = C;
+            sr.off = alloc_raw(sr.bytes(dst.n));
+            dst.st[coff ? 1 : 0] = sr;
+            const int N = dst.n, HW = (int)per_sample, nchunk = sr.chunks;
+            const size_t soff = sr.off;
+            op([=](hipStream_t s) {
+                const float* p[4] = {nullptr, nullptr, nullptr, nullptr};
+                for (int i = 0; i < nsrc; ++i) p[i] = reinterpret_cast<const float*>(h->arena + o[i]);
+                avg_into_stats(p[0], p[1], p[2], p[3], div, N, HW, C, reinterpret_cast<float*>(h->arena + doff), dstC, coff, act,
+                               bmask, reinterpret_cast<double*>(h->arena + soff), nchunk, s);
+            }, 1, nsrc == 4 ? "skip_avg4_concat+stats" : "concat_copy+stats", 0.0, 4.0 * pixels * C * (nsrc + 1));
+            return;
+        }
         op([=](hipStream_t s) {
             const float* p[4] = {nullptr, nullptr, nullptr, nullptr};
             for (int i = 0; i < nsrc; ++i) p[i] = reinterpret_cast<const float*>(h->arena + o[i]);
@@ -759,11 +813,11 @@ struct Builder {
             Tn nxt;
             const Tn* d = li + 1 == layers.size() ? dst : nullptr;   // only the block's last layer writes into the view
             switch (L.kind) {
-                case L_CONV: nxt = conv(nm, cur, L.cout, 3, 1, false, nullptr, nullptr, plane, false, true, d); break;
+                case L_CONV: nxt = conv(nm, cur, L.cout, 3, 1, false, nullptr, nullptr, plane, false, true, d, true); break;
                 case L_RES: nxt = res_block(nm, cur, L.cin, L.cout, L.up, L.down, embs.at(emb_i++), d); break;
                 case L_ATTN: nxt = attn_block(nm, cur, L.heads, hd->cfg.use_new_attention_order != 0, d); break;
-                case L_DOWN: nxt = conv(nm + ".op", cur, L.ch, 3, 2, false, nullptr, nullptr, -1, false, true, d); break;
-                case L_UP: nxt = conv(nm + ".conv", cur, L.ch, 3, 1, true, nullptr, nullptr, -1, false, true, d); break;
+                case L_DOWN: nxt = conv(nm + ".op", cur, L.ch, 3, 2, false, nullptr, nullptr, -1, false, true, d, true); break;
+                case L_UP: nxt = conv(nm + ".conv", cur, L.ch, 3, 1, true, nullptr, nullptr, -1, false, true, d, true); break;
             }
             if (cur_owned && plane < 0) release(cur);
             plane = -1;
@@ -1038,7 +1092,7 @@ void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats, bool 
         }
     };
     Tn c2 = b.alloc(B, h.h, h.w, h.c + hs[0].back().c);
-    b.avg(&h, 1, 1.f, c2, 0, ACT_NONE);
+    b.avg(&h, 1, 1.f, c2, 0, ACT_NONE, /*want_stats=*/true);
     b.release(h);
     for (size_t bi = 0; bi < sp.output_blocks.size(); ++bi) {
         Tn sk[4];
@@ -1048,7 +1102,7 @@ void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats, bool 
         }
         DSD_CHECK(sk[0].h == c2.h && sk[0].w == c2.w, "decoder skip shape mismatch at output_blocks.%zu", bi);
         const int hc = c2.c - sk[0].c;
-        b.avg(sk, 4, 4.f, c2, hc, ACT_NONE);
+        b.avg(sk, 4, 4.f, c2, hc, ACT_NONE, /*want_stats=*/true);   // only taken when the h part brought its statistics
         for (auto& t : sk) b.release(t);
         const bool last = bi + 1 == sp.output_blocks.size();
         Tn next;
@@ -1060,7 +1114,12 @@ void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats, bool 
         size_t ei = 0;
         Tn out = b.block("output_blocks." + std::to_string(bi), sp.output_blocks[bi], c2, /*keep_input=*/false, dembs[bi], ei,
                          -1, last ? nullptr : &next);
-        if (last) h = out; else c2 = next;
+        if (last) {
+            h = out;
+        } else {
+            next.st[0] = out.st[0];   // the block's last convolution wrote h (and its statistics) into the next concat buffer
+            c2 = next;
+        }
     }
     // ---- out = Conv3x3(SiLU(GN(h)))  (model.py:511-515,751)
     Tn a = b.gn_act("out.0", h, ACT_SILU);

@@ -20,10 +20,20 @@ struct Param {
     int region = 0;      // 0 general, 1 emb_layers weights (contiguous), 2 emb_layers biases (contiguous)
 };
 
+// GroupNorm statistics that travel with a tensor: per-column partial sums (kernels.h GnSrc) of its channels [c0, c0+c),
+// written by the op that produced those channels.
+struct StatRef {
+    size_t off = (size_t)-1;   // arena offset of [n][chunks][c][2] doubles
+    int chunks = 0, c0 = 0, c = 0;
+    bool valid() const { return off != (size_t)-1; }
+    size_t bytes(int n) const { return (size_t)n * chunks * c * 2 * sizeof(double); }
+};
+
 // Activation living in the workspace arena (NHWC).
 struct Tn {
     size_t off = (size_t)-1;
     int n = 0, h = 0, w = 0, c = 0;
+    StatRef st[2];   // st[0] covers channels [0, st[0].c); st[1] (concatenated tensors) the rest
     bool valid() const { return off != (size_t)-1; }
     int64_t numel() const { return (int64_t)n * h * w * c; }
     size_t bytes() const { return (size_t)numel() * sizeof(float); }
@@ -118,7 +128,8 @@ struct dsd_handle {
     // whole-forward hipGraph (sampling loops): captured on cap_stream after the first host-launched forward of a plan,
     // replayed on the caller's stream while plan + bound pointers stay the same
     hipEvent_t param_ev = nullptr;   // recorded after every dsd_set_param on the stream it used
-    int use_graph = 1;
+    int use_graph = 0;
+    int fuse_gn_stats = 1;   // GroupNorm statistics from the producing kernel's epilogue (0: always the standalone pass)
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;
     dsd::GraphKey gkey;

@@ -4,17 +4,23 @@
 // openaimodel.py:205-209,229-236,451; UNet_DS_Diff/model.py:155-163,511-513) and nn.LayerNorm in
 // ldm/modules/attention.py:316-318.
 //
-// NHWC: a group's channels are a short contiguous run per pixel, so the statistics pass streams whole
-// pixel rows with 16-byte loads (each thread owns fixed float4 columns -> per-channel fp64 partials in
-// registers), reduces channels -> groups through LDS in a fixed order (deterministic), and writes one
-// (sum, sumsq) fp64 pair per (sample, chunk, group).  gn_finalize folds mean/rstd/gamma/beta (and the
-// FiLM scale/shift of use_scale_shift_norm ResBlocks) into one per-(sample,channel) scale/shift pair,
-// so the apply pass is y = act(x*scale + shift): 1 read + 1 write of the tensor.
+// Statistics are kept as PER-COLUMN partial sums  partial[n][chunk][c] = (sum, sumsq) in fp64 over a chunk of a sample's
+// pixels.  Three producers write that layout: the epilogue of the convolution that produces the tensor (conv_split.hip:
+// the values are in registers there, so the statistics cost no pass over HBM), the skip-average / concat kernel
+// (avg_into_stats below) and, for tensors neither of them covers, the standalone gn_stats pass (NHWC: a thread owns fixed
+// float4 columns and streams whole pixel rows with 16-byte loads, fp64 per-channel partials in registers).  A
+// concatenated tensor simply has two sources (one per part), so group boundaries need not align with the parts.
+// gn_finalize reduces columns x chunks of a group in a fixed order (deterministic) and folds mean/rstd/gamma/beta (and
+// the FiLM scale/shift of use_scale_shift_norm ResBlocks) into one per-(sample,channel) scale/shift pair, so the apply
+// pass is y = act(x*scale + shift): 1 read + 1 write of the tensor.
 #include "kernels.h"
 
 namespace dsd {
 
 static constexpr int GN_GROUPS = 32;
+
+// (A hardware exp2 / reciprocal SiLU was measured: 18.9 -> 18.4 ms per step for ~3e-7 of extra error; not taken.)
+__device__ __forceinline__ float silu_f(float v) { return v / (1.f + expf(-v)); }
 
 struct GnGeom {
     int threads;  // block size
@@ -100,15 +106,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
             sm[((int64_t)row * C + c) * 2 + 1] = q[k][e];
         }
     __syncthreads();
-    if (tid < GN_GROUPS) {
-        const int cpg = C / GN_GROUPS;
+    // rows -> one (sum, sumsq) per column; consecutive threads take consecutive columns (16-byte LDS stride)
+    for (int c = tid; c < C; c += blockDim.x) {
         double ss = 0.0, qq = 0.0;
-        for (int r = 0; r < rpi; ++r)
-            for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-                ss += sm[((int64_t)r * C + c) * 2 + 0];
-                qq += sm[((int64_t)r * C + c) * 2 + 1];
-            }
-        double* o = partial + (((int64_t)n * gridDim.x + chunk) * GN_GROUPS + tid) * 2;
+        for (int r = 0; r < rpi; ++r) {
+            ss += sm[((int64_t)r * C + c) * 2 + 0];
+            qq += sm[((int64_t)r * C + c) * 2 + 1];
+        }
+        double* o = partial + (((int64_t)n * gridDim.x + chunk) * C + c) * 2;
         o[0] = ss;
         o[1] = qq;
     }
@@ -131,43 +136,57 @@ void gn_stats(const float* x, int N, int HW, int C, double* partial, int nchunk,
     check_launch("gn_stats");
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ partial, int nchunk, int HW, int C,
+// One workgroup per (group, sample): sums the group's columns over all chunks of their source (fixed order: thread t takes
+// items t, t+256, ...; then a fixed LDS tree), then writes scale/shift of the group's channels.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(GnSrc s0, GnSrc s1, int HW, int C,
                                                           const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, float eps,
                                                           const float* __restrict__ film, int film_stride,
                                                           float* __restrict__ scale, float* __restrict__ shift) {
-    __shared__ double ps[8][GN_GROUPS][2];
-    __shared__ float mean_s[GN_GROUPS], rstd_s[GN_GROUPS];
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const int g = tid & 31, j = tid >> 5;
-    double ss = 0.0, qq = 0.0;
-    for (int ch = j; ch < nchunk; ch += 8) {
-        const double* o = partial + (((int64_t)n * nchunk + ch) * GN_GROUPS + g) * 2;
-        ss += o[0];
-        qq += o[1];
-    }
-    ps[j][g][0] = ss;
-    ps[j][g][1] = qq;
-    __syncthreads();
-    if (tid < GN_GROUPS) {
-        double a = 0.0, b = 0.0;
-        for (int r = 0; r < 8; ++r) {
-            a += ps[r][tid][0];
-            b += ps[r][tid][1];
-        }
-        const double cnt = (double)HW * (C / GN_GROUPS);
-        const double mean = a / cnt;
-        double var = b / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        mean_s[tid] = (float)mean;
-        rstd_s[tid] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-    __syncthreads();
+    __shared__ double red[256][2];
+    __shared__ float mean_s, rstd_s;
+    const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
     const int cpg = C / GN_GROUPS;
-    for (int c = tid; c < C; c += 256) {
-        const int gg = c / cpg;
-        float sc = rstd_s[gg] * gamma[c];
-        float sh = beta[c] - mean_s[gg] * sc;
+    const int g0 = g * cpg, g1 = g0 + cpg;
+    double ss = 0.0, qq = 0.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const GnSrc& sr = k == 0 ? s0 : s1;
+        if (!sr.p) continue;
+        const int lo = max(g0, sr.c0), hi = min(g1, sr.c0 + sr.c);   // this group's columns inside the source
+        const int ncol = hi - lo;
+        if (ncol <= 0) continue;
+        const int items = sr.chunks * ncol;
+        const double* base = sr.p + (int64_t)n * sr.chunks * sr.c * 2;
+        for (int it = tid; it < items; it += 256) {
+            const int ch = it / ncol, c = lo + (it - ch * ncol) - sr.c0;
+            const double* o = base + ((int64_t)ch * sr.c + c) * 2;
+            ss += o[0];
+            qq += o[1];
+        }
+    }
+    red[tid][0] = ss;
+    red[tid][1] = qq;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) {
+            red[tid][0] += red[tid + st][0];
+            red[tid][1] += red[tid + st][1];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double cnt = (double)HW * cpg;
+        const double mean = red[0][0] / cnt;
+        double var = red[0][1] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s = (float)mean;
+        rstd_s = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = g0 + tid; c < g1; c += 256) {
+        float sc = rstd_s * gamma[c];
+        float sh = beta[c] - mean_s * sc;
         if (film) {  // (GN(x)) * (1 + fscale) + fshift, openaimodel.py:278-279
             const float f = 1.f + film[(int64_t)n * film_stride + c];
             sc *= f;
@@ -178,15 +197,105 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     }
 }
 
-void gn_finalize(const double* partial, int nchunk, int N, int HW, int C, const float* gamma, const float* beta,
+void gn_finalize(const GnSrc& s0, const GnSrc& s1, int N, int HW, int C, const float* gamma, const float* beta,
                  float eps, const float* film, int film_stride, float* scale, float* shift, hipStream_t s) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, s, partial, nchunk, HW, C, gamma, beta, eps, film,
+    DSD_CHECK(s0.p && s0.c0 == 0 && s0.c + (s1.p ? s1.c : 0) == C && (!s1.p || s1.c0 == s0.c),
+              "gn_finalize: the statistic sources do not cover the %d channels", C);
+    if (N == 0) return;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(GN_GROUPS, N), dim3(256), 0, s, s0, s1, HW, C, gamma, beta, eps, film,
                        film_stride, scale, shift);
     check_launch("gn_finalize");
 }
 
-// (A hardware exp2 / reciprocal SiLU was measured: 18.9 -> 18.4 ms per step for ~3e-7 of extra error; not taken.)
-__device__ __forceinline__ float silu_f(float v) { return v / (1.f + expf(-v)); }
+// dst[:, coff:coff+C] = act((a [+b] [+c] [+d]) / div)  (the job of avg_into, misc.hip) AND the per-column statistics of what
+// it wrote, in the geometry of the statistics pass: grid (chunk, sample), a thread owns K fixed float4 columns.
+template <int K, int ACT>
+__global__ __launch_bounds__(256) void avg_stats_kernel(const float4* __restrict__ a, const float4* __restrict__ b,
+                                                        const float4* __restrict__ c, const float4* __restrict__ d,
+                                                        float div, int HW, int C, int rpi, int ppc, float* __restrict__ dst,
+                                                        int dstC, int coff, int bmask, double* __restrict__ partial) {
+    extern __shared__ double sm[];  // [rpi][C][2]
+    const int cols = C >> 2;
+    const int colsk = cols / K;
+    const int tid = threadIdx.x;
+    const int row = tid / colsk;
+    const int col0 = tid - row * colsk;
+    const int n = blockIdx.y, chunk = blockIdx.x;
+    const int p0 = chunk * ppc;
+    const int p1 = min(HW, p0 + ppc);
+    double s[K][4], q[K][4];
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[k][e] = q[k][e] = 0.0;
+    const int64_t sb = (int64_t)n * HW * cols;   // sample base (float4 units); broadcast sources have one sample only
+    for (int p = p0 + row; p < p1; p += rpi) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int c4 = col0 + k * colsk;
+            const int64_t is = (int64_t)p * cols + c4, i = sb + is;
+            float4 v = a[(bmask & 1) ? is : i];
+            if (b) { const float4 t = b[(bmask & 2) ? is : i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (c) { const float4 t = c[(bmask & 4) ? is : i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (d) { const float4 t = d[(bmask & 8) ? is : i]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            if (div != 1.f) { v.x /= div; v.y /= div; v.z /= div; v.w /= div; }
+            if (ACT == ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+            *reinterpret_cast<float4*>(dst + ((int64_t)n * HW + p) * dstC + coff + c4 * 4) = v;
+            const double x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+            s[k][0] += x0; q[k][0] = fma(x0, x0, q[k][0]);
+            s[k][1] += x1; q[k][1] = fma(x1, x1, q[k][1]);
+            s[k][2] += x2; q[k][2] = fma(x2, x2, q[k][2]);
+            s[k][3] += x3; q[k][3] = fma(x3, x3, q[k][3]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int cc = (col0 + k * colsk) * 4 + e;
+            sm[((int64_t)row * C + cc) * 2 + 0] = s[k][e];
+            sm[((int64_t)row * C + cc) * 2 + 1] = q[k][e];
+        }
+    __syncthreads();
+    for (int cc = tid; cc < C; cc += blockDim.x) {
+        double ss = 0.0, qq = 0.0;
+        for (int r = 0; r < rpi; ++r) {
+            ss += sm[((int64_t)r * C + cc) * 2 + 0];
+            qq += sm[((int64_t)r * C + cc) * 2 + 1];
+        }
+        double* o = partial + (((int64_t)n * gridDim.x + chunk) * C + cc) * 2;
+        o[0] = ss;
+        o[1] = qq;
+    }
+}
+
+void avg_into_stats(const float* a, const float* b, const float* c, const float* d, float div, int N, int HW, int C,
+                    float* dst, int dstC, int coff, int act, int bmask, double* partial, int nchunk, hipStream_t s) {
+    DSD_CHECK(C % 4 == 0 && dstC % 4 == 0 && coff % 4 == 0, "avg_into_stats: channel counts must be multiples of 4");
+    if ((int64_t)N * HW * C == 0) return;
+    const GnGeom g = gn_geom(HW, C);
+    DSD_CHECK(g.nchunk == nchunk, "avg_into_stats: chunk count mismatch");
+    const size_t lds = (size_t)g.rpi * C * 2 * sizeof(double);
+    DSD_CHECK(lds <= 64 * 1024, "avg_into_stats: C=%d too large", C);
+    const dim3 grid(g.nchunk, N), block(g.threads);
+#define DSD_AVG(KK)                                                                                                          \
+    if (act == ACT_SILU)                                                                                                     \
+        hipLaunchKernelGGL((avg_stats_kernel<KK, ACT_SILU>), grid, block, lds, s, (const float4*)a, (const float4*)b,        \
+                           (const float4*)c, (const float4*)d, div, HW, C, g.rpi, g.ppc, dst, dstC, coff, bmask, partial);  \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((avg_stats_kernel<KK, ACT_NONE>), grid, block, lds, s, (const float4*)a, (const float4*)b,        \
+                           (const float4*)c, (const float4*)d, div, HW, C, g.rpi, g.ppc, dst, dstC, coff, bmask, partial);
+    switch (g.k) {
+        case 1: DSD_AVG(1) break;
+        case 2: DSD_AVG(2) break;
+        case 3: DSD_AVG(3) break;
+        case 4: DSD_AVG(4) break;
+        default: fail("avg_into_stats: C=%d needs %d columns per thread (unsupported)", C, g.k);
+    }
+#undef DSD_AVG
+    check_launch("avg_into_stats");
+}
+
 
 // y = act(x * scale[n][c] + shift[n][c]).  Like the statistics pass a thread owns fixed float4 columns, so its scale / shift
 // live in registers and the loop body has no index arithmetic beyond one add (the first version recomputed (sample, column)

@@ -101,6 +101,11 @@ int dsd_get_precision(dsd_handle* h);
  * otherwise equal to fp32 rounding, ~1e-7), 28 % fewer FLOPs at batch 16.  It is work the reference performs redundantly, so
  * it is never enabled silently and bench.py reports it as a separate line; dsd_plan_flops() counts what is executed. */
 int dsd_set_share_zero_streams(dsd_handle* h, int on);
+/* GroupNorm statistics (ON by default): every tensor a GroupNorm32 normalises is written by a convolution, or is the
+ * concatenation of a convolution output and the skip average (model.py:743-746), so the per-channel sums are accumulated
+ * in the epilogue of the kernel that writes the tensor and the separate statistics pass over HBM disappears
+ * (openaimodel.py:264-284: "fused GroupNorm" of the north star).  0 = always run the standalone pass (A/B, tests). */
+int dsd_set_fuse_gn_stats(dsd_handle* h, int on);
 /* 0 if every parameter has been set, else -1 with the first missing name in dsd_last_error(). */
 int dsd_params_ready(dsd_handle* h);
 
@@ -135,11 +140,13 @@ int dsd_profile_get(dsd_handle* h, int idx, const char** kind, double* total_ms,
                     int64_t* calls, int* runs);
 
 /* ---- sampling loop ----------------------------------------------------------------------- */
-/* Whole-forward hipGraph replay inside dsd_sample / dsd_sample_dpm (ON by default): the network evaluation of a step is
- * a fixed list of ~1000 launches whose arguments do not change while the loop runs on the same buffers, so it is captured
+/* Whole-forward hipGraph replay inside dsd_sample / dsd_sample_dpm (OFF by default): the network evaluation of a step is
+ * a fixed list of ~800 launches whose arguments do not change while the loop runs on the same buffers, so it can be captured
  * once (after the plan's first host-launched forward) and replayed per step; the reference's Python loop
- * (gaussian_diffusion.py:569-616) pays the launches every step.  Results are bit-identical either way.  dsd_forward and
- * dsd_profile_* always launch from the host. */
+ * (gaussian_diffusion.py:569-616) pays the launches every step.  Results are bit-identical either way.  Measured on MI355X:
+ * the asynchronous host launches already keep the GPU busy (batch 16: 443.7 vs 445.4 ms per step, batch 1: 39.0 vs 40.3), so
+ * replay only takes the launch work off the host thread; hence opt-in.  dsd_forward and dsd_profile_* always launch from
+ * the host. */
 int dsd_set_graph(dsd_handle* h, int on);
 int dsd_graph_stats(dsd_handle* h, int* captures, int* launches);
 /* Optional: the global slice index of every row of the next sampling batches (host array, n = batch size; n = 0 clears).

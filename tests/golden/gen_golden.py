@@ -486,7 +486,27 @@ def gen_dpm():
     save("dpm", **out)
 
 
+def gen_temb():
+    """timestep_embedding (ldm/modules/diffusionmodules/util.py:161-181) with the frequency table AS THIS HOST's torch
+    evaluates it stored beside the outputs: torch's vectorised fp32 exp differs by 1 ulp between CPU ISAs (AVX2 / AVX-512),
+    and sin/cos(t*f) at t ~ 1e3 turn that into ~6e-5, so a bit-level check of the kernel needs the generating host's
+    table (exactly what the shim hands the library through dsd_set_timestep_freqs on whatever host it runs on)."""
+    import math
+    from ldm.modules.diffusionmodules.util import timestep_embedding
+    out = {}
+    t_int = torch.tensor([0, 1, 2, 17, 250, 499, 500, 731, 998, 999])
+    t_float = torch.tensor([0.0, 0.5, 20.0, 499.5, 979.0, 999.0])
+    for dim in (320, 32, 96, 1152):
+        half = dim // 2
+        out[f"freqs_{dim}"] = torch.exp(-math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32) / half).numpy()
+        out[f"int_{dim}"] = timestep_embedding(t_int, dim).numpy()
+        out[f"float_{dim}"] = timestep_embedding(t_float, dim).numpy()
+    out["t_int"] = t_int.numpy()
+    out["t_float"] = t_float.numpy()
+    save("temb", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "ops", "xattn", "model", "loops", "loops2", "dpm"]
+    which = sys.argv[1:] or ["schedules", "ops", "xattn", "model", "loops", "loops2", "dpm", "temb"]
     for w in which:
         globals()["gen_" + w]()

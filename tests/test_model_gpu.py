@@ -330,7 +330,51 @@ def test_full_size_graph_replay_is_bit_identical(full_model):
         after = m.graph_stats()
         assert torch.equal(a, b)
         assert after["launches"] - before["launches"] >= 3, (before, after)     # the graph really ran
-    m.use_graph(True)
+    m.use_graph(False)
+
+
+def test_gn_statistics_from_conv_epilogue_match_the_standalone_pass(B, full_model):
+    """GroupNorm statistics ride in the epilogue of the producing convolution / concat kernel (dsd_set_fuse_gn_stats, on by
+    default).  Both routes sum the same fp32 values, the fused one with fp32 partials of <= 32 terms: they must agree to
+    rounding, and each must hold the block / model tolerances against the reference fixtures and the oracle."""
+    from diffusion_models_dsdiff_amd._lib import lib, check
+    g = golden("ops")
+    emb = randn((2, 128), 20).cuda()
+    # ResBlocks: 16x16 (128-row tiles, 2 chunks) from the fixture; 64x64 x 2 (256-row tiles) fused vs standalone
+    for key, kw, shp, xs in [("res_same", dict(channels=64, out_channels=64), (2, 64, 16, 16), 21),
+                             ("res_skip", dict(channels=32, out_channels=64), (2, 32, 16, 16), 22)]:
+        m = B.ResBlock(emb_channels=128, dropout=0.0, **kw)
+        m.load_state_dict(fixture_params(g, key), strict=True)
+        for on in (1, 0):
+            check(lib().dsd_set_fuse_gn_stats(m._h, on))
+            assert rel_l2(m(randn(shp, xs).cuda(), emb), g[key + "_y"]) < TOL_BLOCK, (key, on)
+        big = randn((2, shp[1], 64, 64), 5).cuda()
+        check(lib().dsd_set_fuse_gn_stats(m._h, 1))
+        y1 = m(big, emb)
+        check(lib().dsd_set_fuse_gn_stats(m._h, 0))
+        y0 = m(big, emb)
+        assert rel_l2(y1, y0) < 5e-7
+    # whole network at 64x64 (decoder concats: two statistic sources per tensor) and at 256x256
+    m, cfg, sd = full_model
+    x, t = randn((1, 2, 64, 64), 5), torch.tensor([731])
+    yo = O.unet_forward(cfg, sd, x, t)[0]
+    ys = {}
+    for on in (True, False):
+        m.fuse_gn_stats(on)
+        ys[on] = m._run(x.cuda(), t.cuda(), want_feats=False)[0]
+        assert rel_l2(ys[on], yo) < 1e-5, on
+        launches = m.plan_info()["launches"]
+        print(f"fuse_gn_stats={on}: {launches} launches per forward, rel-L2 vs oracle {rel_l2(ys[on], yo):.3e}")
+    assert rel_l2(ys[True], ys[False]) < 2e-6
+    x2, t2 = randn((2, 2, 256, 256), 6).cuda(), torch.tensor([10, 900]).cuda()
+    m.fuse_gn_stats(False)
+    y0 = m._run(x2, t2, want_feats=False)[0]
+    n0 = m.plan_info()["launches"]
+    m.fuse_gn_stats(True)
+    y1 = m._run(x2, t2, want_feats=False)[0]
+    n1 = m.plan_info()["launches"]
+    assert rel_l2(y1, y0) < 2e-6 and n1 < n0 - 100, (n0, n1)        # most of the 191 statistics launches are gone
+    assert torch.equal(y1, m._run(x2, t2, want_feats=False)[0])     # deterministic
 
 
 def test_data_edits_are_uploaded():
