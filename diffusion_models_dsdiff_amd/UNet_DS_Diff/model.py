@@ -35,10 +35,14 @@ def _is_zero_init(name: str) -> bool:
 class NativeModule(nn.Module):
     """An nn.Module whose parameters mirror a libdsdiff handle's parameter table."""
 
+    _zero_sites = True     # apply the reference's zero_module() initialisation sites (U-Net blocks); the VAE has none
+    _strip = ""            # prefix of the C-side parameter names that this module's own tree does not carry
+
     def __init__(self):
         super().__init__()
         self._h = C.c_void_p()
         self._uploaded: Dict[str, tuple] = {}
+        self._cname: Dict[str, str] = {}      # python parameter name -> name in the library's table
         self._device_index = 0
 
     # ---- parameter tree from the C-side table (names identical to the reference state_dict)
@@ -49,12 +53,14 @@ class NativeModule(nn.Module):
         fan_in: Dict[str, int] = {}
         for i in range(n):
             check(L.dsd_param_info(self._h, i, C.byref(name), shape, C.byref(ndim)))
-            nm = name.value.decode()
+            cname = name.value.decode()
+            nm = cname[len(self._strip):] if self._strip and cname.startswith(self._strip) else cname
+            self._cname[nm] = cname
             shp = tuple(int(shape[k]) for k in range(ndim.value))
             p = nn.Parameter(torch.empty(shp, dtype=torch.float32), requires_grad=False)
             base = nm.rsplit(".", 1)[0]
             with torch.no_grad():
-                if _is_zero_init(nm):
+                if self._zero_sites and _is_zero_init(nm):
                     p.zero_()
                 elif len(shp) >= 2:                      # nn.Conv*/nn.Linear default: kaiming_uniform(a=sqrt(5))
                     fi = int(torch.tensor(shp[1:]).prod())
@@ -162,7 +168,7 @@ class NativeModule(nn.Module):
                 t = t.float()
             t = t.contiguous()
             shp = (C.c_int64 * max(1, t.dim()))(*t.shape)
-            check(L.dsd_set_param(self._h, nm.encode(), C.c_void_p(t.data_ptr()), shp, t.dim(), int(t.is_cuda),
+            check(L.dsd_set_param(self._h, self._cname.get(nm, nm).encode(), C.c_void_p(t.data_ptr()), shp, t.dim(), int(t.is_cuda),
                                   stream_ptr() if t.is_cuda else None))
             self._uploaded[nm] = key
         if torch.cuda.is_available():

@@ -643,6 +643,14 @@ int dsd_op_linear(const float* x, int N, int K, const float* w, const float* bia
     DSD_CATCH
 }
 
+int dsd_op_gaussian_sample(const float* moments, const float* noise, uint64_t philox_seed, int B, int E, int H, int W, float* z,
+                           void* stream) {
+    DSD_TRY
+    DSD_CHECK(moments && z && B >= 0 && E >= 1 && H >= 1 && W >= 1, "bad argument");
+    gaussian_sample(moments, noise, philox_seed, B, E, H * W, z, (hipStream_t)stream);
+    DSD_CATCH
+}
+
 int dsd_op_philox_normal(float* y, int64_t n, uint64_t seed, uint64_t step, void* stream) {
     DSD_TRY
     philox_normal(y, n, seed, step, (hipStream_t)stream);

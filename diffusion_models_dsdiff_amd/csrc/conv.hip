@@ -558,9 +558,8 @@ void pack_ohwi(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, hi
 }
 
 double conv2d_flops(const ConvArgs& a) {
-    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W;
-    const int pad = a.ks / 2;
-    const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
+    int OH, OW;
+    conv_out_hw(a, &OH, &OW);
     return 2.0 * a.N * OH * OW * (double)a.Cout * a.ks * a.ks * a.Cin;
 }
 
@@ -613,8 +612,8 @@ static int effective_precision(const ConvArgs& a, int tiles_m) {
 
 size_t conv2d_scratch_bytes(const ConvArgs& a) {
     if (a.precision == PREC_F32 || a.Cin % 32 != 0 || a.Cin % 4 != 0) return 0;
-    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
-    const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
+    int OH, OW;
+    conv_out_hw(a, &OH, &OW);
     const int64_t M = (int64_t)a.N * OH * OW;
     const int tm = cdiv(M, BM);
     if (effective_precision(a, tm) == PREC_F32) return 0;
@@ -627,8 +626,8 @@ int conv2d_stats_chunks(const ConvArgs& a) {
     // only the split-precision implicit-GEMM kernels carry the statistics epilogue (and not their split-K form, whose
     // output is written by the reduction kernel)
     if (a.out_nchw || a.Cin % 4 != 0 || a.ks * a.ks * a.Cin < 32) return 0;
-    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
-    const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
+    int OH, OW;
+    conv_out_hw(a, &OH, &OW);
     const int64_t M = (int64_t)a.N * OH * OW;
     const int tm = cdiv(M, BM);
     const int pr = effective_precision(a, tm);
@@ -642,8 +641,8 @@ int conv2d_stats_chunks(const ConvArgs& a) {
 }
 
 void conv2d_plan_query(const ConvArgs& a, int* structure, int* nt_out, int* ks_out) {
-    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
-    const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
+    int OH, OW;
+    conv_out_hw(a, &OH, &OW);
     const int tm = cdiv((int64_t)a.N * OH * OW, BM);
     const int pr = effective_precision(a, tm);
     int nt = pick_nt(a.Cout, tm, pr), ks = 1, ad = -1;
@@ -659,8 +658,8 @@ const char* conv2d_variant(const ConvArgs& a) {
         if (a.Cout % 4 == 0 && a.Cout / 4 <= 256 && Ktot <= 9 && !a.out_nchw && (!a.emb || a.emb_stride % 4 == 0)) return "conv_direct_cols";
         return (a.Cout % 4 == 0 && (size_t)Ktot * a.Cout * 4 <= 60 * 1024) ? "conv_direct_lds" : "conv_scalar";
     }
-    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
-    const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
+    int OH, OW;
+    conv_out_hw(a, &OH, &OW);
     static const char* names[4][6] = {{"", "conv_mfma<1>", "conv_mfma<2>", "conv_mfma<3>", "conv_mfma<4>", "conv_mfma<5>"},
                                       {"", "conv_bf16x3<1>", "conv_bf16x3<2>", "conv_bf16x3<3>", "conv_bf16x3<4>", "conv_bf16x3<5>"},
                                       {"", "conv_bf16x6<1>", "conv_bf16x6<2>", "conv_bf16x6<3>", "conv_bf16x6<4>", "conv_bf16x6<5>"},
@@ -685,12 +684,11 @@ void conv2d(ConvArgs a, hipStream_t s) {
     p.x = a.x; p.w = a.w; p.bias = a.bias; p.emb = a.emb; p.res = a.res; p.y = a.y;
     p.N = a.N; p.H = a.H; p.W = a.W; p.Cin = a.Cin; p.Cout = a.Cout; p.ks = a.ks; p.stride = a.stride;
     p.y_ld = a.y_ld > 0 ? a.y_ld : a.Cout;
-    p.pad = a.ks / 2; p.ups = a.ups; p.emb_stride = a.emb_stride; p.out_nchw = a.out_nchw;
+    p.pad = a.pad_lo >= 0 ? a.pad_lo : a.ks / 2; p.ups = a.ups; p.emb_stride = a.emb_stride; p.out_nchw = a.out_nchw;
     p.x_bs = a.x_bs >= 0 ? a.x_bs : (int64_t)a.H * a.W * a.Cin;
     p.IHg = a.ups ? a.H * 2 : a.H;
     p.IWg = a.ups ? a.W * 2 : a.W;
-    p.OH = (p.IHg + 2 * p.pad - a.ks) / a.stride + 1;
-    p.OW = (p.IWg + 2 * p.pad - a.ks) / a.stride + 1;
+    conv_out_hw(a, &p.OH, &p.OW);
     p.ohw = p.OH * p.OW;
     const int64_t M64 = (int64_t)a.N * p.ohw;
     DSD_CHECK(M64 < (1ll << 31) && M64 * std::max(a.Cout, a.Cin) < (1ll << 40), "conv2d: problem too large");

@@ -202,14 +202,14 @@ __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&a
 // blocks: combined through the (now idle) LDS in a fixed order, so the result is deterministic.  One (sum, sumsq) pair per
 // column and block tile; the tile lies inside one sample (host guarantees ohw % tile rows == 0).
 template <int NT>
-__device__ __forceinline__ void stats_reduce(const SplitP& p, const float (&cs)[NT], const float (&cq)[NT], unsigned char* lds,
+__device__ __forceinline__ void stats_reduce(const SplitP& p, const double (&cs)[NT], const double (&cq)[NT], unsigned char* lds,
                                              int m0, int n0, int tile_rows, int tid, int wave, int lrow, int half) {
     constexpr int BROWS = NT * 32;
     double* red = reinterpret_cast<double*>(lds);   // [4 waves][BROWS][2]
     __syncthreads();                                 // every wave is done with the operand tiles in LDS
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
-        double s = (double)cs[j], q = (double)cq[j];
+        double s = cs[j], q = cq[j];
         s += __shfl_xor(s, 32);
         q += __shfl_xor(q, 32);
         if (half == 0) {
@@ -410,10 +410,16 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
 
     if (p.stats) {
         float cs[NT], cq[NT];
+        double ds[NT], dq[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) cs[j] = cq[j] = 0.f;
         split_epilogue<NT, true>(p, acc, m0, n0, wave, lrow, half, SBM, cs, cq);
-        stats_reduce<NT>(p, cs, cq, lds, m0, n0, SBM, tid, wave, lrow, half);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            ds[j] = (double)cs[j];
+            dq[j] = (double)cq[j];
+        }
+        stats_reduce<NT>(p, ds, dq, lds, m0, n0, SBM, tid, wave, lrow, half);
         return;
     }
     split_epilogue<NT>(p, acc, m0, n0, wave, lrow, half);
@@ -698,12 +704,24 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         return;
     }
     if (p.stats) {
-        float cs[NT], cq[NT];
+        // fp32 partials cover ONE 32-row block (16 rows per lane) whatever the tile structure, everything above is fp64:
+        // the statistics do not depend on the 128 / 256-row choice beyond fp64 rounding
+        double ds[NT], dq[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) cs[j] = cq[j] = 0.f;
+        for (int j = 0; j < NT; ++j) ds[j] = dq[j] = 0.0;
 #pragma unroll
-        for (int r = 0; r < RB; ++r) split_epilogue<NT, true>(p, acc[r], m0, n0, wave * RB + r, lrow, half, SBM * RB, cs, cq);
-        stats_reduce<NT>(p, cs, cq, Bs, m0, n0, SBM * RB, tid, wave, lrow, half);
+        for (int r = 0; r < RB; ++r) {
+            float cs[NT], cq[NT];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) cs[j] = cq[j] = 0.f;
+            split_epilogue<NT, true>(p, acc[r], m0, n0, wave * RB + r, lrow, half, SBM * RB, cs, cq);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                ds[j] += (double)cs[j];
+                dq[j] += (double)cq[j];
+            }
+        }
+        stats_reduce<NT>(p, ds, dq, Bs, m0, n0, SBM * RB, tid, wave, lrow, half);
         return;
     }
 #pragma unroll
@@ -826,8 +844,8 @@ static int split_structure(const ConvArgs& a, int M) {
 // Measured (tools/bench_conv.py): batch 1, 8x8 960->960: 0.096 -> 0.027 ms, whole step 52.0 -> 40 ms; batch 16, 8x8
 // 960->960: 0.161 (nt 1, x2) -> 0.109 ms (nt 3, x6).  Grids that fill the chip anyway keep nt_default and ksplit = 1.
 void conv2d_split_plan(const ConvArgs& a, int nt_default, int* nt_out, int* ks_out, int* ad_out, bool allow_split) {
-    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W, pad = a.ks / 2;
-    const int OH = (IHg + 2 * pad - a.ks) / a.stride + 1, OW = (IWg + 2 * pad - a.ks) / a.stride + 1;
+    int OH, OW;
+    conv_out_hw(a, &OH, &OW);
     const int64_t M = (int64_t)a.N * OH * OW;
     int ad0 = split_structure(a, (int)std::min<int64_t>(M, 1 << 30));
     *nt_out = nt_default;
@@ -875,13 +893,12 @@ void conv2d_split(const ConvArgs& a, int nt, int ksplit, int ad, hipStream_t s) 
     SplitP p{};
     p.x = a.x; p.w = a.w_split; p.bias = a.bias; p.emb = a.emb; p.res = a.res; p.y = a.y;
     p.N = a.N; p.H = a.H; p.W = a.W; p.Cin = a.Cin; p.Cout = a.Cout; p.ks = a.ks; p.stride = a.stride;
-    p.pad = a.ks / 2; p.ups = a.ups; p.emb_stride = a.emb_stride; p.out_nchw = a.out_nchw;
+    p.pad = a.pad_lo >= 0 ? a.pad_lo : a.ks / 2; p.ups = a.ups; p.emb_stride = a.emb_stride; p.out_nchw = a.out_nchw;
     p.y_ld = a.y_ld > 0 ? a.y_ld : a.Cout;
     p.x_bs = a.x_bs >= 0 ? a.x_bs : (int64_t)a.H * a.W * a.Cin;
     p.IHg = a.ups ? a.H * 2 : a.H;
     p.IWg = a.ups ? a.W * 2 : a.W;
-    p.OH = (p.IHg + 2 * p.pad - a.ks) / a.stride + 1;
-    p.OW = (p.IWg + 2 * p.pad - a.ks) / a.stride + 1;
+    conv_out_hw(a, &p.OH, &p.OW);
     p.ohw = p.OH * p.OW;
     p.M = (int)((int64_t)a.N * p.ohw);
     p.Ktot = a.ks * a.ks * a.Cin;

@@ -13,6 +13,7 @@ struct ConvArgs {
     const float* w = nullptr;   // packed OHWI: [Cout][ks*ks*Cin]
     const float* bias = nullptr;
     int Cout = 0, ks = 3, stride = 1;
+    int pad_lo = -1, pad_total = -1;   // padding before the first row/column and in total per axis (-1: ks/2 and 2*(ks/2))
     int ups = 0;                // nearest x2 folded into the gather (Upsample, openaimodel.py:111-121)
     const float* emb = nullptr; // per-(n,co) add: emb[n*emb_stride + co]   (ResBlock h + emb_out, openaimodel.py:282)
     int emb_stride = 0;
@@ -33,6 +34,15 @@ struct ConvArgs {
     double* stats = nullptr;
     int stats_chunks = 0;
 };
+// Output size.  Default padding is ks/2 on every side (the U-Net's convolutions); pad_lo / pad_total describe the VAE's
+// Downsample (ldm/modules/diffusionmodules/model.py:78-83: F.pad (0,1,0,1) then a stride-2 conv with padding 0), i.e. no
+// padding before the first row / column and one zero row / column after the last.
+inline void conv_out_hw(const ConvArgs& a, int* OH, int* OW) {
+    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W;
+    const int pt = a.pad_total >= 0 ? a.pad_total : 2 * (a.ks / 2);
+    *OH = (IHg + pt - a.ks) / a.stride + 1;
+    *OW = (IWg + pt - a.ks) / a.stride + 1;
+}
 // chunks per sample the kernel conv2d() will launch for these arguments can emit output statistics with (0 = it cannot:
 // the caller runs gn_stats on the output instead)
 int conv2d_stats_chunks(const ConvArgs& a);
@@ -101,6 +111,8 @@ void nhwc_to_nchw(const float* x, int N, int C, int HW, float* y, hipStream_t s)
 void avgpool2(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);
 void upsample2(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);
 void geglu(const float* x, int64_t rows, int inner, float* y, hipStream_t s);
+// in place: s[r][:] = softmax(s[r][:] * scale) over `cols` contiguous fp32 (one workgroup per row; max-subtracted, fp32)
+void softmax_rows(float* s, int64_t rows, int cols, float scale, hipStream_t st);
 void add2(const float* a, const float* b, int64_t n, float* y, hipStream_t s);
 
 // ---------------------------------------------------------------- sampler.hip
@@ -126,6 +138,9 @@ void dpm_step(const DpmCoef& c, const float* model_out, int Cm, float* x, float*
               float ratio, float max_val, int B, int HW, hipStream_t s);
 void dpm_threshold(const float* x0, float* y, float* s_buf, float ratio, float max_val, int B, int n, hipStream_t s);
 void philox_normal(float* y, int64_t n, uint64_t seed, uint64_t step, hipStream_t s);
+// DiagonalGaussianDistribution.sample (ldm/modules/distributions/distributions.py:24-37): moments [B,2E,HW] (NCHW) ->
+// z = mean + exp(0.5 * clamp(logvar, -30, 20)) * eps, eps = noise[B,E,HW] or Philox normals (noise == nullptr)
+void gaussian_sample(const float* moments, const float* noise, uint64_t seed, int B, int E, int HW, float* z, hipStream_t s);
 void fill_t(float* t, int B, float v, hipStream_t s);
 
 }  // namespace dsd

@@ -262,6 +262,37 @@ void geglu(const float* x, int64_t rows, int inner, float* y, hipStream_t s) {
     check_launch("geglu");
 }
 
+// row softmax for the materialised score matrix of the VAE's single-head attention (model.py:196-198)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(float* __restrict__ s, int cols, float scale) {
+    __shared__ float red[4];
+    float* row = s + (int64_t)blockIdx.x * cols;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float m = -INFINITY;
+    for (int c = tid; c < cols; c += 256) m = fmaxf(m, row[c] * scale);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = tid; c < cols; c += 256) {
+        const float e = expf(row[c] * scale - m);
+        row[c] = e;
+        sum += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = (red[0] + red[1]) + (red[2] + red[3]);
+    const float inv = 1.f / sum;
+    for (int c = tid; c < cols; c += 256) row[c] *= inv;
+}
+void softmax_rows(float* s, int64_t rows, int cols, float scale, hipStream_t st) {
+    if (rows == 0 || cols == 0) return;
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, st, s, cols, scale);
+    check_launch("softmax_rows");
+}
+
 __global__ void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ y) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = a[i] + b[i];
 }

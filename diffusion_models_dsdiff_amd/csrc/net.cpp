@@ -245,6 +245,90 @@ void p_btb(dsd_handle* h, const std::string& p, int dim, int heads, int dh, int 
 
 std::string pre(const std::string& p, const std::string& n) { return p.empty() ? n : p + "." + n; }
 
+// ---- KL-VAE (ldm/modules/diffusionmodules/model.py:452-655, ldm/models/autoencoder.py:26-147)
+// iargs: ch, out_ch, in_channels, resolution, z_channels, double_z, embed_dim, num_res_blocks, with_quant, n_mult, mult[..],
+//        n_attn, attn_resolutions[..]   (the ddconfig of configs/autoencoder_kl_64x64x3.yaml:14-24 + embed_dim)
+struct VaeCfg {
+    int ch, out_ch, in_ch, resolution, z, double_z, embed, nrb, with_quant;
+    std::vector<int> mult, attn_res;
+    bool attn_at(int res) const { return std::find(attn_res.begin(), attn_res.end(), res) != attn_res.end(); }
+};
+VaeCfg vae_cfg(const std::vector<int32_t>& a) {
+    DSD_CHECK(a.size() >= 11, "VAE handle needs >= 11 integer arguments");
+    VaeCfg c;
+    c.ch = a[0]; c.out_ch = a[1]; c.in_ch = a[2]; c.resolution = a[3]; c.z = a[4]; c.double_z = a[5]; c.embed = a[6];
+    c.nrb = a[7]; c.with_quant = a[8];
+    const int nm = a[9];
+    DSD_CHECK(nm >= 1 && nm <= 8 && (int)a.size() >= 11 + nm, "VAE: bad ch_mult");
+    for (int i = 0; i < nm; ++i) c.mult.push_back(a[10 + i]);
+    const int na = a[10 + nm];
+    DSD_CHECK(na >= 0 && (int)a.size() >= 11 + nm + na, "VAE: bad attn_resolutions");
+    for (int i = 0; i < na; ++i) c.attn_res.push_back(a[11 + nm + i]);
+    DSD_CHECK(c.ch % 32 == 0 && c.ch >= 32, "VAE: ch = %d must be a multiple of 32 (GroupNorm(32))", c.ch);
+    DSD_CHECK(c.nrb >= 1 && c.z >= 1 && c.in_ch >= 1 && c.out_ch >= 1 && c.embed >= 1, "VAE: bad configuration");
+    return c;
+}
+void p_vae_res(dsd_handle* h, const std::string& p, int cin, int cout) {
+    p_norm(h, p + ".norm1", cin);
+    p_conv(h, p + ".conv1", cin, cout, 3);
+    p_norm(h, p + ".norm2", cout);
+    p_conv(h, p + ".conv2", cout, cout, 3);
+    if (cin != cout) p_conv(h, p + ".nin_shortcut", cin, cout, 1);
+}
+void p_vae_attn(dsd_handle* h, const std::string& p, int c) {
+    p_norm(h, p + ".norm", c);
+    for (const char* n : {"q", "k", "v", "proj_out"}) p_conv(h, p + "." + n, c, c, 1);
+}
+void p_vae_encoder(dsd_handle* h, const VaeCfg& c) {   // model.py:452-517
+    const std::string e = "encoder";
+    p_conv(h, e + ".conv_in", c.in_ch, c.ch, 3);
+    int res = c.resolution, block_in = c.ch;
+    for (size_t l = 0; l < c.mult.size(); ++l) {
+        block_in = c.ch * (l == 0 ? 1 : c.mult[l - 1]);
+        const int block_out = c.ch * c.mult[l];
+        for (int j = 0; j < c.nrb; ++j) {
+            p_vae_res(h, e + ".down." + std::to_string(l) + ".block." + std::to_string(j), block_in, block_out);
+            block_in = block_out;
+            if (c.attn_at(res)) p_vae_attn(h, e + ".down." + std::to_string(l) + ".attn." + std::to_string(j), block_in);
+        }
+        if (l + 1 != c.mult.size()) {
+            p_conv(h, e + ".down." + std::to_string(l) + ".downsample.conv", block_in, block_in, 3);
+            res /= 2;
+        }
+    }
+    p_vae_res(h, e + ".mid.block_1", block_in, block_in);
+    p_vae_attn(h, e + ".mid.attn_1", block_in);
+    p_vae_res(h, e + ".mid.block_2", block_in, block_in);
+    p_norm(h, e + ".norm_out", block_in);
+    p_conv(h, e + ".conv_out", block_in, c.double_z ? 2 * c.z : c.z, 3);
+    if (c.with_quant) p_conv(h, "quant_conv", 2 * c.z, 2 * c.embed, 1);   // autoencoder.py:53
+}
+void p_vae_decoder(dsd_handle* h, const VaeCfg& c) {   // model.py:546-616
+    const std::string d = "decoder";
+    const int L = (int)c.mult.size();
+    if (c.with_quant) p_conv(h, "post_quant_conv", c.embed, c.z, 1);      // autoencoder.py:54
+    int block_in = c.ch * c.mult[L - 1];
+    int res = c.resolution >> (L - 1);
+    p_conv(h, d + ".conv_in", c.z, block_in, 3);
+    p_vae_res(h, d + ".mid.block_1", block_in, block_in);
+    p_vae_attn(h, d + ".mid.attn_1", block_in);
+    p_vae_res(h, d + ".mid.block_2", block_in, block_in);
+    for (int l = L - 1; l >= 0; --l) {
+        const int block_out = c.ch * c.mult[l];
+        for (int j = 0; j < c.nrb + 1; ++j) {
+            p_vae_res(h, d + ".up." + std::to_string(l) + ".block." + std::to_string(j), block_in, block_out);
+            block_in = block_out;
+            if (c.attn_at(res)) p_vae_attn(h, d + ".up." + std::to_string(l) + ".attn." + std::to_string(j), block_in);
+        }
+        if (l != 0) {
+            p_conv(h, d + ".up." + std::to_string(l) + ".upsample.conv", block_in, block_in, 3);
+            res *= 2;
+        }
+    }
+    p_norm(h, d + ".norm_out", block_in);
+    p_conv(h, d + ".conv_out", block_in, c.out_ch, 3);
+}
+
 }  // namespace
 
 float* dsd_handle::P(const std::string& name) const {
@@ -308,6 +392,8 @@ void dsd::net_declare_params(dsd_handle* h) {
                 if (a[5]) p_lin(h, "proj_out", a[0], inner); else p_conv(h, "proj_out", inner, a[0], 1);
                 break;
             }
+            case DSD_BLOCK_VAE_ENCODER: p_vae_encoder(h, vae_cfg(a)); break;
+            case DSD_BLOCK_VAE_DECODER: p_vae_decoder(h, vae_cfg(a)); break;
             default: fail("unknown block kind %d", h->block_kind);
         }
         // block parameter names carry no leading '.'
@@ -503,16 +589,17 @@ struct Builder {
     // of a tensor of its own — the decoder's cat([h, skip]) without the copy of h; the returned Tn is then a view of *dst.
     Tn conv(const std::string& name, const Tn& x, int cout, int ks, int stride = 1, bool ups = false,
             const EmbRef* emb = nullptr, const Tn* res = nullptr, int plane = -1, bool to_out = false, bool bias = true,
-            const Tn* dst = nullptr, bool want_stats = false) {
+            const Tn* dst = nullptr, bool want_stats = false, int pad_lo = -1, int pad_total = -1) {
         ConvArgs a;
         a.N = x.n; a.H = x.h; a.W = x.w; a.Cin = x.c; a.Cout = cout; a.ks = ks; a.stride = stride; a.ups = ups ? 1 : 0;
+        a.pad_lo = pad_lo; a.pad_total = pad_total;
         a.w = W(name + ".weight");
         a.bias = bias ? W(name + ".bias") : nullptr;
         const Param& pw = hd->PP(name + ".weight");
         DSD_CHECK(pw.numel == (int64_t)cout * x.c * ks * ks, "conv %s: weight has %lld elements, graph expects %dx%dx%dx%d",
                   name.c_str(), (long long)pw.numel, cout, x.c, ks, ks);
-        const int IHg = ups ? x.h * 2 : x.h, IWg = ups ? x.w * 2 : x.w, pad = ks / 2;
-        const int OH = (IHg + 2 * pad - ks) / stride + 1, OW = (IWg + 2 * pad - ks) / stride + 1;
+        int OH, OW;
+        conv_out_hw(a, &OH, &OW);
         Tn y;
         if (dst) {
             DSD_CHECK(!to_out && dst->n == x.n && dst->h == OH && dst->w == OW && dst->c >= cout && dst->c % 4 == 0,
@@ -904,6 +991,80 @@ struct Builder {
         return x3;
     }
 
+    // ---------------------------------------------------------------- KL-VAE blocks (ldm/modules/diffusionmodules/model.py)
+    // ResnetBlock.forward with temb = None (:121-149); GroupNorm eps 1e-6 (Normalize :41-42).  x stays owned by the caller.
+    Tn vae_res(const std::string& p, const Tn& x, int cout) {
+        Tn a = gn_act(p + ".norm1", x, ACT_SILU, 1e-6f);
+        Tn h = conv(p + ".conv1", a, cout, 3, 1, false, nullptr, nullptr, -1, false, true, nullptr, true);
+        release(a);
+        Tn a2 = gn_act(p + ".norm2", h, ACT_SILU, 1e-6f);
+        release(h);
+        Tn skip = x;
+        const bool proj = x.c != cout;
+        if (proj) skip = conv(p + ".nin_shortcut", x, cout, 1);
+        Tn out = conv(p + ".conv2", a2, cout, 3, 1, false, nullptr, &skip, -1, false, true, nullptr, true);
+        release(a2);
+        if (proj) release(skip);
+        return out;
+    }
+    // AttnBlock.forward (:185-209): ONE head over all C channels, softmax(q k^T C^-1/2) v.  C is 512 at the yaml's size, far
+    // beyond the flash kernel's head dims, so the score matrix is materialised per sample and both products run as GEMMs
+    // on the convolution kernels (a 1x1 convolution whose "weights" are the other operand: y[m][n] = sum_k A[m][k] B[n][k]).
+    Tn vae_attn(const std::string& p, const Tn& x) {
+        const int C = x.c, T = x.hw(), Bn = x.n;
+        Tn n = gn_act(p + ".norm", x, ACT_NONE, 1e-6f);
+        Tn q = conv(p + ".q", n, C, 1), k = conv(p + ".k", n, C, 1), v = conv(p + ".v", n, C, 1);
+        release(n);
+        Tn a = alloc(Bn, x.h, x.w, C);
+        const bool split = hd->precision != PREC_F32 && C % 32 == 0 && T % 32 == 0;
+        const bool f16 = hd->precision == PREC_F16X3;
+        const size_t sb = (size_t)T * T * sizeof(float), vb = (size_t)C * T * sizeof(float), pb = split ? (size_t)T * C * 6 : 0;
+        const size_t soff = alloc_raw(sb), vtoff = alloc_raw(vb), poff = pb ? alloc_raw(pb) : 0;
+        if (split && f16 && !hd->ovf) {
+            DSD_HIP(hipMalloc((void**)&hd->ovf, sizeof(int)));
+            DSD_HIP(hipMemset(hd->ovf, 0, sizeof(int)));
+        }
+        const size_t qo = q.off, ko = k.off, vo = v.off, ao = a.off;
+        const int prec = hd->precision;
+        const float scale = 1.f / std::sqrt((float)C);   // int(c)**(-0.5), :196
+        dsd_handle* h = hd;
+        const double fl = 4.0 * Bn * (double)T * T * C;
+        plan.flops += fl;
+        op([=](hipStream_t s) {
+            float* S = reinterpret_cast<float*>(h->arena + soff);
+            float* vt = reinterpret_cast<float*>(h->arena + vtoff);
+            void* planes = pb ? static_cast<void*>(h->arena + poff) : nullptr;
+            auto gemm_nt = [&](const float* A, const float* Bm, float* Y, int M, int N, int K) {
+                ConvArgs c;
+                c.x = A; c.N = 1; c.H = M; c.W = 1; c.Cin = K; c.w = Bm; c.Cout = N; c.ks = 1; c.y = Y;
+                if (split) {
+                    split_weights(Bm, (int64_t)N * K, 3, planes, s, f16, f16 ? h->ovf : nullptr);
+                    c.w_split = planes;
+                    c.precision = prec;
+                    c.ovf = f16 ? h->ovf : nullptr;
+                }
+                conv2d(c, s);
+            };
+            for (int b = 0; b < Bn; ++b) {
+                const float* qb = reinterpret_cast<const float*>(h->arena + qo) + (size_t)b * T * C;
+                const float* kb = reinterpret_cast<const float*>(h->arena + ko) + (size_t)b * T * C;
+                const float* vb_ = reinterpret_cast<const float*>(h->arena + vo) + (size_t)b * T * C;
+                float* ab = reinterpret_cast<float*>(h->arena + ao) + (size_t)b * T * C;
+                gemm_nt(qb, kb, S, T, T, C);            // w_[i][j] = sum_c q[i][c] k[j][c]                     :194-195
+                softmax_rows(S, T, T, scale, s);         // * C^-1/2, softmax over j                             :196-197
+                nhwc_to_nchw(vb_, 1, C, T, vt, s);       // v^T [C][T]
+                gemm_nt(S, vt, ab, T, C, T);            // h_[i][c] = sum_j w_[i][j] v[j][c]                    :200-203
+            }
+        }, Bn * (split ? 6 : 4), "vae_attention", fl);
+        release_raw(soff, sb);
+        release_raw(vtoff, vb);
+        if (pb) release_raw(poff, pb);
+        release(q); release(k); release(v);
+        Tn out = conv(p + ".proj_out", a, C, 1, 1, false, nullptr, &x, -1, false, true, nullptr, true);
+        release(a);
+        return out;
+    }
+
     // copy an external device buffer (io.*) into the arena, optionally NCHW -> NHWC
     Tn import_ext(int which, int n, int h, int w, int c, bool from_nchw) {
         Tn t = alloc(n, h, w, c);
@@ -1194,6 +1355,95 @@ void build_block(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
             y = b.conv("proj_out", t, a[0], 1, 1, false, nullptr, &x);
             b.release(t);
             for (auto& c : ctx) b.release(c);
+            break;
+        }
+        case DSD_BLOCK_VAE_ENCODER: {   // Encoder.forward (model.py:519-543) [+ quant_conv, autoencoder.py:138-142]
+            const VaeCfg c = vae_cfg(a);
+            const int L = (int)c.mult.size();
+            DSD_CHECK(C == c.in_ch, "VAE encoder: input has %d channels, expected %d", C, c.in_ch);
+            DSD_CHECK(H % (1 << (L - 1)) == 0 && W % (1 << (L - 1)) == 0, "VAE encoder: H=%d, W=%d must be multiples of %d", H, W, 1 << (L - 1));
+            const std::string e = "encoder";
+            Tn hcur = b.conv(e + ".conv_in", x, c.ch, 3, 1, false, nullptr, nullptr, -1, false, true, nullptr, true);
+            int res = c.resolution;
+            for (int l = 0; l < L; ++l) {
+                for (int j = 0; j < c.nrb; ++j) {
+                    Tn t = b.vae_res(e + ".down." + std::to_string(l) + ".block." + std::to_string(j), hcur, c.ch * c.mult[l]);
+                    b.release(hcur);
+                    hcur = t;
+                    if (c.attn_at(res)) {
+                        Tn t2 = b.vae_attn(e + ".down." + std::to_string(l) + ".attn." + std::to_string(j), hcur);
+                        b.release(hcur);
+                        hcur = t2;
+                    }
+                }
+                if (l != L - 1) {   // Downsample :78-83: zero row/column AFTER the last one, stride 2, no padding before
+                    Tn t = b.conv(e + ".down." + std::to_string(l) + ".downsample.conv", hcur, hcur.c, 3, 2, false, nullptr, nullptr,
+                                  -1, false, true, nullptr, true, /*pad_lo=*/0, /*pad_total=*/1);
+                    b.release(hcur);
+                    hcur = t;
+                    res /= 2;
+                }
+            }
+            Tn t = b.vae_res(e + ".mid.block_1", hcur, hcur.c);
+            b.release(hcur);
+            Tn t2 = b.vae_attn(e + ".mid.attn_1", t);
+            b.release(t);
+            Tn t3 = b.vae_res(e + ".mid.block_2", t2, t2.c);
+            b.release(t2);
+            Tn n = b.gn_act(e + ".norm_out", t3, ACT_SILU, 1e-6f);
+            b.release(t3);
+            y = b.conv(e + ".conv_out", n, c.double_z ? 2 * c.z : c.z, 3);
+            b.release(n);
+            if (c.with_quant) {
+                Tn m = b.conv("quant_conv", y, 2 * c.embed, 1);
+                b.release(y);
+                y = m;
+            }
+            break;
+        }
+        case DSD_BLOCK_VAE_DECODER: {   // [post_quant_conv, autoencoder.py:144-147 +] Decoder.forward (model.py:618-655)
+            const VaeCfg c = vae_cfg(a);
+            const int L = (int)c.mult.size();
+            DSD_CHECK(C == (c.with_quant ? c.embed : c.z), "VAE decoder: input has %d channels, expected %d", C, c.with_quant ? c.embed : c.z);
+            const std::string d = "decoder";
+            Tn zin = x;
+            bool zin_owned = false;
+            if (c.with_quant) {
+                zin = b.conv("post_quant_conv", x, c.z, 1);
+                zin_owned = true;
+            }
+            Tn hcur = b.conv(d + ".conv_in", zin, c.ch * c.mult[L - 1], 3, 1, false, nullptr, nullptr, -1, false, true, nullptr, true);
+            if (zin_owned) b.release(zin);
+            Tn t = b.vae_res(d + ".mid.block_1", hcur, hcur.c);
+            b.release(hcur);
+            Tn t2 = b.vae_attn(d + ".mid.attn_1", t);
+            b.release(t);
+            hcur = b.vae_res(d + ".mid.block_2", t2, t2.c);
+            b.release(t2);
+            int res = c.resolution >> (L - 1);
+            for (int l = L - 1; l >= 0; --l) {
+                for (int j = 0; j < c.nrb + 1; ++j) {
+                    Tn r = b.vae_res(d + ".up." + std::to_string(l) + ".block." + std::to_string(j), hcur, c.ch * c.mult[l]);
+                    b.release(hcur);
+                    hcur = r;
+                    if (c.attn_at(res)) {
+                        Tn r2 = b.vae_attn(d + ".up." + std::to_string(l) + ".attn." + std::to_string(j), hcur);
+                        b.release(hcur);
+                        hcur = r2;
+                    }
+                }
+                if (l != 0) {
+                    Tn r = b.conv(d + ".up." + std::to_string(l) + ".upsample.conv", hcur, hcur.c, 3, 1, true, nullptr, nullptr, -1,
+                                  false, true, nullptr, true);
+                    b.release(hcur);
+                    hcur = r;
+                    res *= 2;
+                }
+            }
+            Tn n = b.gn_act(d + ".norm_out", hcur, ACT_SILU, 1e-6f);
+            b.release(hcur);
+            y = b.conv(d + ".conv_out", n, c.out_ch, 3);
+            b.release(n);
             break;
         }
         default: fail("unknown block kind");

@@ -264,6 +264,28 @@ void dpm_threshold(const float* x0, float* y, float* s_buf, float ratio, float m
     DSD_HIP(hipStreamSynchronize(s));
 }
 
+__global__ void gaussian_sample_kernel(const float* __restrict__ mo, const float* __restrict__ noise, uint64_t seed, int B, int E,
+                                       int HW, float* __restrict__ z) {
+    const int64_t total = (int64_t)B * E * HW;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / ((int64_t)E * HW);
+        const int64_t r = i - b * E * HW;                       // (e, p) inside the sample
+        const float mean = mo[b * 2 * E * HW + r];
+        float logvar = mo[b * 2 * E * HW + (int64_t)E * HW + r];
+        logvar = fminf(fmaxf(logvar, -30.f), 20.f);             // distributions.py:28
+        const float std = expf(0.5f * logvar);
+        const float eps = noise ? noise[i] : philox_normal_at(i, seed, 0);
+        z[i] = mean + std * eps;                                // :36
+    }
+}
+void gaussian_sample(const float* moments, const float* noise, uint64_t seed, int B, int E, int HW, float* z, hipStream_t s) {
+    const int64_t total = (int64_t)B * E * HW;
+    if (!total) return;
+    hipLaunchKernelGGL(gaussian_sample_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, moments,
+                       noise, seed, B, E, HW, z);
+    check_launch("gaussian_sample");
+}
+
 __global__ void fill_t_kernel(float* t, int B, float v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B) t[i] = v;

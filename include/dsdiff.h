@@ -228,13 +228,21 @@ int dsd_op_dpm_threshold(const float* x0, int B, int n, float ratio, float max_v
 /* ---- single blocks (own parameter namespace, names relative to the block) ----------------- */
 enum { DSD_BLOCK_RES = 0, DSD_BLOCK_ATTN = 1, DSD_BLOCK_UPSAMPLE = 2, DSD_BLOCK_DOWNSAMPLE = 3,
        DSD_BLOCK_DISENTANGLE = 4, DSD_BLOCK_SE = 5, DSD_BLOCK_CROSSATTN = 6, DSD_BLOCK_FF_GEGLU = 7,
-       DSD_BLOCK_BASIC_TRANSFORMER = 8, DSD_BLOCK_SPATIAL_TRANSFORMER = 9 };
+       DSD_BLOCK_BASIC_TRANSFORMER = 8, DSD_BLOCK_SPATIAL_TRANSFORMER = 9,
+       /* latent path (SURVEY f-3): the KL-VAE of ldm/models/autoencoder.py:26-147 — Encoder / Decoder of
+        * ldm/modules/diffusionmodules/model.py:452-655 with quant_conv / post_quant_conv; parameter names are the
+        * AutoencoderKL state_dict's ("encoder.down.0.block.0.norm1.weight", "quant_conv.weight", ...) */
+       DSD_BLOCK_VAE_ENCODER = 10, DSD_BLOCK_VAE_DECODER = 11 };
 /* iargs by kind:
  *   RES: cin, cout, emb_ch, use_scale_shift_norm, up, down      ATTN: ch, heads, new_order
  *   UPSAMPLE/DOWNSAMPLE: ch     DISENTANGLE: ch, half_ch       SE: ch, reduction
  *   CROSSATTN: query_dim, context_dim, heads, dim_head          FF_GEGLU: dim, mult
  *   BASIC_TRANSFORMER: dim, heads, dim_head, context_dim
- *   SPATIAL_TRANSFORMER: in_ch, heads, dim_head, depth, context_dim, use_linear */
+ *   SPATIAL_TRANSFORMER: in_ch, heads, dim_head, depth, context_dim, use_linear
+ *   VAE_ENCODER / VAE_DECODER: ch, out_ch, in_channels, resolution, z_channels, double_z, embed_dim, num_res_blocks,
+ *        with_quant (1: AutoencoderKL.encode / decode incl. quant_conv / post_quant_conv, 0: bare Encoder / Decoder),
+ *        len(ch_mult), ch_mult..., len(attn_resolutions), attn_resolutions...    (configs/autoencoder_kl_64x64x3.yaml:14-24)
+ *        encoder: x [B,in_channels,H,W] -> moments [B,2*embed_dim,H/f,W/f];  decoder: z [B,embed_dim,h,w] -> [B,out_ch,h*f,w*f] */
 int dsd_block_create(int kind, const int32_t* iargs, int n_iargs, int device, dsd_handle** out);
 /* x: NCHW [B,C,H,W] (token blocks: [B,N,C] passed as H=N, W=1 "NHWC"), aux: emb [B,emb_ch] for RES,
  * context [B,Nc,Cc] for cross-attention kinds (aux2/aux_len2 = second context for depth-2 spatial
@@ -277,6 +285,10 @@ int dsd_op_timestep_embedding(const void* t, int t_is_float, int N, int dim, con
 /* y[N,O] = act_in(x[N,K]) @ w[O,K]^T + bias ; act_in: 0 none, 1 SiLU. */
 int dsd_op_linear(const float* x, int N, int K, const float* w, const float* bias, int O, int act_in, float* y,
                   void* stream);
+/* DiagonalGaussianDistribution(moments).sample() (ldm/modules/distributions/distributions.py:24-37): moments [B,2E,H,W]
+ * -> z [B,E,H,W] = mean + exp(0.5*clamp(logvar,-30,20)) * eps; eps = noise [B,E,H,W] or on-device Philox normals. */
+int dsd_op_gaussian_sample(const float* moments, const float* noise_or_null, uint64_t philox_seed, int B, int E, int H, int W,
+                           float* z, void* stream);
 /* Philox4x32-10 + Box-Muller stream used by dsd_sample when noise == NULL: fills n normals. */
 int dsd_op_philox_normal(float* y, int64_t n, uint64_t seed, uint64_t step, void* stream);
 

@@ -486,6 +486,49 @@ def gen_dpm():
     save("dpm", **out)
 
 
+VAE_SMALL = dict(double_z=True, z_channels=3, resolution=32, in_channels=1, out_ch=1, ch=32, ch_mult=[1, 2, 4], num_res_blocks=1,
+                 attn_resolutions=[8], dropout=0.0)
+VAE_RGB = dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=64, ch_mult=[1, 2], num_res_blocks=2,
+               attn_resolutions=[], dropout=0.0)
+
+
+def gen_vae():
+    """Latent path (SURVEY f-3): the reference's Encoder / Decoder (ldm/modules/diffusionmodules/model.py:452-655) and
+    DiagonalGaussianDistribution, run on CPU; AutoencoderKL (Lightning + diffusers) does not import, so its quant_conv /
+    post_quant_conv (autoencoder.py:53-54,138-147) are applied here with F.conv2d on synthetic weights."""
+    import torch.nn.functional as F
+    from ldm.modules.diffusionmodules.model import Encoder, Decoder
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    out = {}
+    for key, dd, embed, xshape, seed in (("small", VAE_SMALL, 3, (2, 1, 32, 32), 300), ("rgb", VAE_RGB, 4, (1, 3, 32, 48), 301)):
+        enc, dec = Encoder(**dd), Decoder(**dd)
+        enc.eval(), dec.eval()
+        ns = [("encoder." + k, tuple(v.shape)) for k, v in enc.state_dict().items()]
+        ns += [("decoder." + k, tuple(v.shape)) for k, v in dec.state_dict().items()]
+        ns += [("quant_conv.weight", (2 * embed, 2 * dd["z_channels"], 1, 1)), ("quant_conv.bias", (2 * embed,)),
+               ("post_quant_conv.weight", (dd["z_channels"], embed, 1, 1)), ("post_quant_conv.bias", (dd["z_channels"],))]
+        sd = synth_params(ns, seed)
+        enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}, strict=True)
+        dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}, strict=True)
+        f = 2 ** (len(dd["ch_mult"]) - 1)
+        x = randn(xshape, seed + 10)
+        h = enc(x)
+        moments = F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
+        post = DiagonalGaussianDistribution(moments)
+        torch.manual_seed(seed + 20)
+        z = post.sample()
+        torch.manual_seed(seed + 20)
+        noise = torch.randn(post.mean.shape)           # what sample() drew (distributions.py:36)
+        zin = randn((xshape[0], embed, xshape[2] // f, xshape[3] // f), seed + 30)
+        zdec = dec(F.conv2d(zin, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"]))
+        zraw = randn((xshape[0], dd["z_channels"], xshape[2] // f, xshape[3] // f), seed + 40)
+        out.update({f"{key}_cfg": json.dumps(dict(dd, embed_dim=embed)), f"{key}_params": json.dumps([[n, list(s_)] for n, s_ in ns]),
+                    f"{key}_seed": seed, f"{key}_xshape": np.asarray(xshape), f"{key}_enc_h": h.numpy(),
+                    f"{key}_moments": moments.numpy(), f"{key}_noise": noise.numpy(), f"{key}_z": z.numpy(),
+                    f"{key}_decode": zdec.numpy(), f"{key}_dec_raw": dec(zraw).numpy()})
+    save("vae", **out)
+
+
 def gen_temb():
     """timestep_embedding (ldm/modules/diffusionmodules/util.py:161-181) with the frequency table AS THIS HOST's torch
     evaluates it stored beside the outputs: torch's vectorised fp32 exp differs by 1 ulp between CPU ISAs (AVX2 / AVX-512),
@@ -507,6 +550,6 @@ def gen_temb():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "ops", "xattn", "model", "loops", "loops2", "dpm", "temb"]
+    which = sys.argv[1:] or ["schedules", "ops", "xattn", "model", "loops", "loops2", "dpm", "temb", "vae"]
     for w in which:
         globals()["gen_" + w]()

@@ -88,3 +88,28 @@ def test_bad_config_is_rejected():
     h = C.c_void_p()
     assert _lib.lib().dsd_create(C.byref(cfg), -1, C.byref(h)) != 0
     assert b"in_channels" in _lib.lib().dsd_last_error()
+
+
+def test_vae_parameter_tables_match_reference_names():
+    """Table-only VAE handles (device = -1): encoder + quant_conv and post_quant_conv + decoder carry exactly the
+    parameter names / shapes of the reference's Encoder / Decoder / AutoencoderKL (tests/golden/vae.npz)."""
+    import json
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "vae.npz"))
+    L = _lib.lib()
+    for key in ("small", "rgb"):
+        dd = json.loads(str(g[key + "_cfg"]))
+        ia = [dd["ch"], dd["out_ch"], dd["in_channels"], dd["resolution"], dd["z_channels"], 1, dd["embed_dim"], dd["num_res_blocks"], 1,
+              len(dd["ch_mult"])] + dd["ch_mult"] + [len(dd["attn_resolutions"])] + dd["attn_resolutions"]
+        got = {}
+        for kind in (_lib.BLOCK_VAE_ENCODER, _lib.BLOCK_VAE_DECODER):
+            h = C.c_void_p()
+            arr = (C.c_int32 * len(ia))(*ia)
+            _lib.check(L.dsd_block_create(kind, arr, len(ia), -1, C.byref(h)))
+            name, shape, ndim = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+            for i in range(L.dsd_param_count(h)):
+                _lib.check(L.dsd_param_info(h, i, C.byref(name), shape, C.byref(ndim)))
+                got[name.value.decode()] = tuple(shape[k] for k in range(ndim.value))
+            L.dsd_destroy(h)
+        ref = {n: tuple(s) for n, s in json.loads(str(g[key + "_params"]))}
+        assert got == ref

@@ -307,3 +307,29 @@ def test_dpm_multistep_loops():
         ns = dpm.NoiseSchedule(**dpm_case_betas(src))
         y = dpm.dpm_multistep(net, ns, xT.clone(), model_type=mtype, **kw)
         assert rel_l2(y, g[key + "_y"]) < TOL_LOOP, key
+
+
+# ------------------------------------------------------------------ latent path (SURVEY f-3): KL-VAE
+@pytest.mark.parametrize("key", ["small", "rgb"])
+def test_vae_oracle_matches_reference_fixtures(key):
+    """oracle/vae.py against the reference's own Encoder / Decoder / DiagonalGaussianDistribution outputs
+    (tests/golden/vae.npz, produced by gen_golden.py::gen_vae on CPU)."""
+    import json
+    from oracle import vae as V
+    from util import golden, fixture_params, rel_l2, randn
+    g = golden("vae")
+    cfg = V.VaeConfig(**json.loads(str(g[key + "_cfg"])))
+    sd = fixture_params(g, key)
+    seed = int(g[key + "_seed"])
+    xshape = tuple(int(v) for v in g[key + "_xshape"])
+    f = 2 ** (len(cfg.ch_mult) - 1)
+    x = randn(xshape, seed + 10)
+    assert rel_l2(V.encoder(cfg, sd, x), g[key + "_enc_h"]) < 2e-6
+    m = V.encode(cfg, sd, x)
+    assert rel_l2(m, g[key + "_moments"]) < 2e-6
+    z = V.gaussian_sample(torch.from_numpy(g[key + "_moments"]), torch.from_numpy(g[key + "_noise"]))
+    assert torch.equal(z, torch.from_numpy(g[key + "_z"]))                       # same three fp32 ops
+    zin = randn((xshape[0], cfg.embed_dim, xshape[2] // f, xshape[3] // f), seed + 30)
+    assert rel_l2(V.decode(cfg, sd, zin), g[key + "_decode"]) < 2e-6
+    zraw = randn((xshape[0], cfg.z_channels, xshape[2] // f, xshape[3] // f), seed + 40)
+    assert rel_l2(V.decoder(cfg, sd, zraw), g[key + "_dec_raw"]) < 2e-6

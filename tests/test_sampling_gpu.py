@@ -131,8 +131,7 @@ def test_philox_sampling_is_seeded_and_batch_independent(env):
 
 
 def test_share_zero_streams_is_bit_identical(env):
-    """Optional dedup of the two all-zero-input streams (dsd_set_share_zero_streams): same bits here (the tiny model picks
-    the same kernels at batch 1 and 4; at full size the choice can differ -> test_full_size_properties), fewer FLOPs."""
+    """Optional dedup of the two all-zero-input streams (dsd_set_share_zero_streams): the same result with fewer FLOPs."""
     from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
     gl, wrap, cond, xT, _ = env
     d = create_gaussian_diffusion(steps=1000, timestep_respacing="20", rescale_timesteps=True, parameterization="v")
@@ -149,7 +148,13 @@ def test_share_zero_streams_is_bit_identical(env):
         b = d.p_sample_loop(wrap, shape, **kw)
         f1 = unet.plan_info()["flops"]
         unet.share_zero_streams(False)
-        assert torch.equal(a, b), prec
+        # f32: no kernel's arithmetic depends on the batch -> same bits.  Split modes: the GroupNorm statistics ride in the
+        # convolution epilogues (fp32 partials per 32-row block, fp64 above), and the batch-1 streams pick other tiles than
+        # the batch-4 ones, so the sums are ordered differently: equal to fp64-rounding of the statistics only
+        if prec == "f32":
+            assert torch.equal(a, b), prec
+        else:
+            assert rel_l2(b, a) < 1e-6, prec
         assert f1 < 0.85 * f0
     unet.set_precision("bf16x6")
 

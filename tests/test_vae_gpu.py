@@ -1,0 +1,126 @@
+"""Latent path (BASELINE config 4): the KL-VAE of ldm/models/autoencoder.py on the native kernels, through
+the C ABI (DSD_BLOCK_VAE_ENCODER / DSD_BLOCK_VAE_DECODER, dsd_op_gaussian_sample).
+
+Fixtures come from the reference's own Encoder / Decoder / DiagonalGaussianDistribution (tests/golden/vae.npz,
+gen_golden.py::gen_vae); tolerance 1e-5 rel-L2 on encode / decode outputs (fp32 re-association over ~25 layers), bit-exact
+for the three-op posterior sample given the same moments and noise.  At the yaml's own size (ch 128, 256x256, single-head
+attention over 512 channels x 4096 tokens) the GPU path is checked against the oracle run live."""
+import json
+
+import pytest
+import torch
+
+from oracle import vae as V
+from util import golden, fixture_params, rel_l2, randn
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _case(key):
+    g = golden("vae")
+    dd = json.loads(str(g[key + "_cfg"]))
+    sd = fixture_params(g, key)
+    seed = int(g[key + "_seed"])
+    xshape = tuple(int(v) for v in g[key + "_xshape"])
+    return g, dd, sd, seed, xshape
+
+
+@pytest.mark.parametrize("key", ["small", "rgb"])
+def test_encoder_decoder_modules_golden(key):
+    """Bare Encoder / Decoder with the reference's constructor keywords and state_dict names."""
+    from diffusion_models_dsdiff_amd.ldm.modules.diffusionmodules.model import Encoder, Decoder
+    g, dd, sd, seed, xshape = _case(key)
+    embed = dd.pop("embed_dim")
+    f = 2 ** (len(dd["ch_mult"]) - 1)
+    enc, dec = Encoder(**dd), Decoder(**dd)
+    ref_enc = sorted(k[len("encoder."):] for k in sd if k.startswith("encoder."))
+    ref_dec = sorted(k[len("decoder."):] for k in sd if k.startswith("decoder."))
+    assert sorted(enc.state_dict().keys()) == ref_enc and sorted(dec.state_dict().keys()) == ref_dec
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}, strict=True)
+    dec.load_state_dict({k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}, strict=True)
+    for prec, tol in (("bf16x6", TOL), ("f32", TOL), ("bf16x3", 1e-4)):
+        enc.set_precision(prec), dec.set_precision(prec)
+        h = enc(randn(xshape, seed + 10).cuda())
+        assert h.shape == g[key + "_enc_h"].shape and rel_l2(h, g[key + "_enc_h"]) < tol, (key, prec)
+        zraw = randn((xshape[0], dd["z_channels"], xshape[2] // f, xshape[3] // f), seed + 40)
+        y = dec(zraw.cuda())
+        assert y.shape == g[key + "_dec_raw"].shape and rel_l2(y, g[key + "_dec_raw"]) < tol, (key, prec)
+
+
+@pytest.mark.parametrize("key", ["small", "rgb"])
+def test_autoencoder_kl_encode_sample_decode_golden(key):
+    from diffusion_models_dsdiff_amd.ldm.models.autoencoder import AutoencoderKL
+    g, dd, sd, seed, xshape = _case(key)
+    embed = dd.pop("embed_dim")
+    f = 2 ** (len(dd["ch_mult"]) - 1)
+    m = AutoencoderKL(dd, None, embed, train_from_hgf=(dd["in_channels"] != 1))
+    assert sorted(m.state_dict().keys()) == sorted(sd.keys())              # the reference's checkpoint names
+    m.load_state_dict(sd, strict=True)
+    x = randn(xshape, seed + 10).cuda()
+    post = m.encode(x)
+    assert rel_l2(post.parameters, g[key + "_moments"]) < TOL
+    # the posterior sample: same three fp32 ops on the same moments and noise -> same bits
+    from diffusion_models_dsdiff_amd.ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    p2 = DiagonalGaussianDistribution(torch.from_numpy(g[key + "_moments"]).cuda())
+    z = p2.sample(noise=torch.from_numpy(g[key + "_noise"]).cuda())
+    assert torch.equal(z.cpu(), torch.from_numpy(g[key + "_z"]))
+    assert torch.equal(p2.mode().cpu(), torch.from_numpy(g[key + "_moments"])[:, :embed])
+    z1, z2, z3 = p2.sample(seed=5), p2.sample(seed=5), p2.sample(seed=6)    # Philox path: deterministic per seed
+    assert torch.equal(z1, z2) and not torch.equal(z1, z3)
+    eps = (z1 - p2.mean) / p2.std
+    assert abs(float(eps.mean())) < 0.2 and abs(float(eps.std()) - 1) < 0.2
+    zin = randn((xshape[0], embed, xshape[2] // f, xshape[3] // f), seed + 30)
+    y = m.decode(zin.cuda())
+    assert y.shape == g[key + "_decode"].shape and rel_l2(y, g[key + "_decode"]) < TOL
+    rec, post2 = m(x, sample_posterior=False)                               # forward = decode(mode(encode(x)))
+    assert rel_l2(rec, V.decode(V.VaeConfig(**dd, embed_dim=embed), sd, torch.from_numpy(g[key + "_moments"])[:, :embed])) < 1e-4
+
+
+def test_autoencoder_kl_yaml_size_vs_oracle():
+    """configs/autoencoder_kl_64x64x3.yaml ddconfig itself (ch 128, ch_mult [1,2,4], 2 res blocks, z 3, embed 3; the
+    reference forces 1 input / output channel) on a 256x256 slice: encode -> moments [1,6,64,64], decode -> [1,1,256,256]
+    against the oracle run live (mid attention: one head, 512 channels, 4096 tokens -> materialised scores + two GEMMs)."""
+    import yaml, os
+    from diffusion_models_dsdiff_amd.ldm.models.autoencoder import AutoencoderKL
+    from oracle.synth import synth_params
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "configs", "autoencoder_kl_64x64x3.yaml")))["model"]["params"]
+    dd, embed = dict(cfg["ddconfig"]), cfg["embed_dim"]
+    m = AutoencoderKL(dd, cfg.get("lossconfig"), embed)
+    dd["in_channels"], dd["out_ch"] = 1, 1
+    sd = synth_params([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 77)
+    m.load_state_dict(sd, strict=True)
+    vc = V.VaeConfig(**dd, embed_dim=embed)
+    x = randn((1, 1, 256, 256), 78)
+    mo = V.encode(vc, sd, x)
+    zin = randn((1, embed, 64, 64), 79)
+    yo = V.decode(vc, sd, zin)
+    for prec, tol in (("bf16x6", TOL), ("f32", TOL)):
+        m.set_precision(prec)
+        post = m.encode(x.cuda())
+        assert post.parameters.shape == (1, 2 * embed, 64, 64)
+        e1 = rel_l2(post.parameters, mo)
+        y = m.decode(zin.cuda())
+        e2 = rel_l2(y, yo)
+        print(f"AutoencoderKL at the yaml's size, {prec}: encode rel-L2 {e1:.3e}, decode rel-L2 {e2:.3e}")
+        assert e1 < tol and e2 < tol, prec
+    # batch independence + determinism at batch 2
+    x2 = torch.cat([x, randn((1, 1, 256, 256), 80)]).cuda()
+    p2 = m.encode(x2).parameters
+    assert rel_l2(p2[:1], mo) < TOL and torch.equal(p2, m.encode(x2).parameters)
+
+
+def test_vae_rejects_bad_input():
+    from diffusion_models_dsdiff_amd import _lib
+    from diffusion_models_dsdiff_amd.ldm.modules.diffusionmodules.model import Encoder
+    g, dd, sd, seed, xshape = _case("small")
+    dd.pop("embed_dim")
+    enc = Encoder(**dd)
+    enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")}, strict=True)
+    with pytest.raises(_lib.DsdError):
+        enc(torch.zeros(1, 3, 32, 32).cuda())          # wrong channel count
+    with pytest.raises(_lib.DsdError):
+        enc(torch.zeros(1, 1, 30, 32).cuda())          # not a multiple of 2^(levels-1)
+    with pytest.raises(_lib.DsdError):
+        enc(torch.zeros(1, 1, 32, 32))                 # CPU tensor: no CPU fallback
