@@ -97,6 +97,11 @@ class NativeModule(nn.Module):
         check(lib().dsd_set_graph(self._h, int(on)))
         return self
 
+    def winograd(self, on: bool = True):
+        """bf16x6 only: F(2,3)-along-W kernel for the large 3x3 stride-1 convolutions (include/dsdiff.h: dsd_set_winograd)."""
+        check(lib().dsd_set_winograd(self._h, int(on)))
+        return self
+
     def fuse_gn_stats(self, on: bool = True):
         """GroupNorm statistics from the producing kernel's epilogue (default) or from the standalone pass."""
         check(lib().dsd_set_fuse_gn_stats(self._h, int(on)))

@@ -243,6 +243,16 @@ int dsd_set_fuse_gn_stats(dsd_handle* h, int on) {
     DSD_CATCH
 }
 
+int dsd_set_winograd(dsd_handle* h, int on) {
+    DSD_TRY
+    DSD_CHECK(h, "null handle");
+    if (h->use_winograd != (on != 0)) {
+        h->use_winograd = on != 0;
+        h->plan.valid = false;
+    }
+    DSD_CATCH
+}
+
 int dsd_graph_stats(dsd_handle* h, int* captures, int* launches) {
     DSD_TRY
     DSD_CHECK(h, "null handle");
@@ -528,6 +538,8 @@ int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride,
     a.x = x.as<float>(); a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.w = w.as<float>(); a.bias = b.as<float>();
     a.Cout = Cout; a.ks = ks; a.stride = stride; a.y = y.as<float>(); a.variant = variant >= 10 ? -1 : variant;
     Tmp planes(nw * 2 * 3);
+    const bool wino = variant == 50;   // 50 = bf16x6, F(2,3) along the width (conv_wino.hip)
+    if (wino) variant = 11;
     if (variant >= 40) {  // 40 = bf16x3, 41 = bf16x6, 42 = f16x3 on the 256-row A-direct tile (forced)
         a.variant = 32;
         variant -= 30;
@@ -542,6 +554,13 @@ int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride,
         a.precision = variant == 10 ? PREC_BF16X3 : (variant == 11 ? PREC_BF16X6 : PREC_F16X3);
         split_weights(w.as<float>(), (int64_t)nw, 3, planes.p, s, a.precision == PREC_F16X3);
         a.w_split = planes.p;
+    }
+    Tmp wpk(wino ? wino_packed_bytes(Cout, Cin) : 256);
+    if (wino) {
+        DSD_CHECK(conv2d_wino_shape_ok(a), "this shape cannot run on the F(2,3) kernel");
+        // the library keeps weights OHWI: random data is layout-agnostic here (timing only)
+        wino_pack_weights(w.as<float>(), Cout, Cin, wpk.p, s);
+        a.w_wino = wpk.p;
     }
     Tmp scratch(conv2d_scratch_bytes(a));
     a.scratch = scratch.as<float>();
@@ -584,6 +603,13 @@ int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float
         if (precision & 16) a.variant = 30;   // force the A-direct structure
         if (precision & 32) a.variant = 31;   // force the staged structure
         if (precision & 64) a.variant = 32;   // force the 256-row A-direct tile
+    }
+    Tmp wpk((precision & 128) ? wino_packed_bytes(Cout, Cin) + 256 : 256);
+    if (precision & 128) {                    // F(2,3)-along-W kernel (conv_wino.hip); fails loudly if the shape cannot take it
+        DSD_CHECK(conv2d_wino_shape_ok(a), "conv2d: this problem cannot run on the F(2,3) kernel (3x3, stride 1, even width, "
+                                           "Cin %% 16 == 0, Cout %% 32 == 0, >= 4096 output pixels, bf16x6)");
+        wino_pack_weights(wp.as<float>(), Cout, Cin, wpk.p, s);
+        a.w_wino = wpk.p;
     }
     Tmp scratch(conv2d_scratch_bytes(a));
     a.scratch = scratch.as<float>();

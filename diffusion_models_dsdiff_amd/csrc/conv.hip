@@ -612,6 +612,7 @@ static int effective_precision(const ConvArgs& a, int tiles_m) {
 
 size_t conv2d_scratch_bytes(const ConvArgs& a) {
     if (a.precision == PREC_F32 || a.Cin % 32 != 0 || a.Cin % 4 != 0) return 0;
+    if (conv2d_wino_eligible(a)) return 0;
     int OH, OW;
     conv_out_hw(a, &OH, &OW);
     const int64_t M = (int64_t)a.N * OH * OW;
@@ -626,6 +627,7 @@ int conv2d_stats_chunks(const ConvArgs& a) {
     // only the split-precision implicit-GEMM kernels carry the statistics epilogue (and not their split-K form, whose
     // output is written by the reduction kernel)
     if (a.out_nchw || a.Cin % 4 != 0 || a.ks * a.ks * a.Cin < 32) return 0;
+    if (conv2d_wino_eligible(a)) return conv2d_wino_stats_chunks(a);
     int OH, OW;
     conv_out_hw(a, &OH, &OW);
     const int64_t M = (int64_t)a.N * OH * OW;
@@ -634,7 +636,7 @@ int conv2d_stats_chunks(const ConvArgs& a) {
     if (pr == PREC_F32) return 0;
     int nt = pick_nt(a.Cout, tm, pr), ks = 1, ad = 0;
     conv2d_split_plan(a, nt, &nt, &ks, &ad);
-    if (ks > 1) return 0;
+    if (ks > 1 || (ad == 1 && nt >= 4)) return 0;   // (128-row kernels with >= 4 column tiles have no registers for it)
     const int rows = ad == 2 ? 2 * BM : BM;
     const int ohw = OH * OW;
     return ohw % rows == 0 ? ohw / rows : 0;
@@ -667,6 +669,7 @@ const char* conv2d_variant(const ConvArgs& a) {
     const int tm = cdiv((int64_t)a.N * OH * OW, BM);
     const int pr = effective_precision(a, tm);
     int nt = pick_nt(a.Cout, tm, pr), ks = 1, ad = 2;
+    if (pr == PREC_BF16X6 && conv2d_wino_eligible(a)) return "conv_wino_bf16x6";
     if (pr == PREC_F32) return names[pr][nt];
     conv2d_split_plan(a, nt, &nt, &ks, &ad);
     // the 256-row A-direct kernel keeps the plain name; the other structures and split-K runs are separate kinds, so that a
@@ -717,6 +720,10 @@ void conv2d(ConvArgs a, hipStream_t s) {
     }
     const int prec = effective_precision(a, p.tiles_m);
     int nt = pick_nt(a.Cout, p.tiles_m, prec);
+    if (prec == PREC_BF16X6 && conv2d_wino_eligible(a)) {
+        conv2d_wino(a, s);
+        return;
+    }
     if (prec != PREC_F32) {
         int ks = 1, ad = 0;
         // a caller without scratch (never the planned graph) gets the unsplit configuration

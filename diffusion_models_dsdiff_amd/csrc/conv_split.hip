@@ -115,13 +115,47 @@ __device__ __forceinline__ void split4(f32x4 v, u32x2 (&out)[NP], int* ovf = nul
 }
 
 // ---- accumulators -> memory: bias + per-(sample,channel) embedding + residual (same fusion as the fp32 kernel)
-// STATS: every stored value is also added (fp32, this lane's 16 rows of its NT columns) into cs / cq = sum / sum of squares
-// of the column: the GroupNorm statistics of the tensor being written, reduced further by stats_reduce below.  Rounding
-// of the 16-to-32-term fp32 partials is unbiased and is averaged over the >= 60 partials of a group (sum beyond that is
-// fp64), so the statistics stay at fp64 quality for the purposes of the 2e-6 GroupNorm tolerance.
+// STATS: the GroupNorm statistics of the tensor being written.  Every stored value v of this lane's (up to) 16 rows of a
+// column goes into SHIFTED fp32 partials  cs = sum(v - ref), cq = sum((v - ref)^2)  with ref = the lane's first value of
+// that column (StatAcc); the caller turns them into plain fp64 (sum, sum of squares) per 32-row block (stat_flush) and
+// everything above is fp64.  The shift matters: var = E[x^2] - mean^2 cancels, and unshifted fp32 partials would carry
+// their 1e-7 relative error on E[x^2] (measured: 9e-5 on the network output for zero-variance groups, rstd = 316); shifted,
+// the fp32 error is relative to the VARIANCE of 16 neighbouring values, and a constant channel gives exactly zero.
+template <int NT>
+struct StatAcc {
+    float ref[NT], cs[NT], cq[NT];
+    int rows;        // values per column added by this lane (the same for every column it owns at all)
+    unsigned first;  // bit j: column j has no reference value yet (ragged tiles only; interior tiles know it statically)
+    __device__ __forceinline__ void clear() {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) ref[j] = cs[j] = cq[j] = 0.f;
+        rows = 0;
+        first = ~0u;
+    }
+    // first: compile-time "this is the lane's first value of column j" (the loops around the calls are fully unrolled)
+    __device__ __forceinline__ void add(int j, float v, bool first) {
+        if (first) ref[j] = v;
+        const float d = v - ref[j];
+        cs[j] += d;
+        cq[j] = fmaf(d, d, cq[j]);
+    }
+    // plain (sum, sum of squares) of the values added so far, in fp64:  sum = S + n r,  sumsq = Q + 2 r S + n r^2
+    // (a column the lane never stored to has ref = cs = cq = 0 and contributes 0 whatever `rows` says)
+    __device__ __forceinline__ void flush(double (&ds)[NT], double (&dq)[NT]) {
+        const double n = (double)rows;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const double r = (double)ref[j], S = (double)cs[j];
+            ds[j] += S + n * r;
+            dq[j] += (double)cq[j] + 2.0 * r * S + n * r * r;
+        }
+        clear();
+    }
+};
+
 template <int NT, bool STATS = false>
 __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&acc)[NT], int m0, int n0, int wave, int lrow,
-                                               int half, int tile_rows, float (&cs)[NT], float (&cq)[NT]) {
+                                               int half, int tile_rows, StatAcc<NT>& st, bool first_block = true) {
     constexpr int BROWS = NT * 32;
     const bool interior = (m0 + tile_rows <= p.M) && (n0 + BROWS <= p.Cout) && !p.out_nchw;
     if (interior) {
@@ -150,6 +184,7 @@ __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&a
             }
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
+                if (STATS && g == 3 && rr == 3) st.rows += 16;
                 float* yp = p.y + (int64_t)(mb + rr) * p.y_ld + n0 + lrow;
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
@@ -157,10 +192,7 @@ __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&a
                     if (p.emb) v += ev[rr][j];
                     if (p.res) v += rv[rr][j];
                     yp[j * 32] = v;
-                    if (STATS) {
-                        cs[j] += v;
-                        cq[j] = fmaf(v, v, cq[j]);
-                    }
+                    if (STATS) st.add(j, v, first_block && g == 0 && rr == 0);
                 }
             }
         }
@@ -170,6 +202,7 @@ __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&a
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
         if (m >= p.M) continue;
+        if (STATS) st.rows += 1;
         const int nb = m / p.ohw;
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
@@ -179,9 +212,9 @@ __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&a
             if (p.bias) v += p.bias[n];
             if (p.emb) v += p.emb[(int64_t)nb * p.emb_stride + n];
             if (p.res) v += p.res[(int64_t)m * p.Cout + n];
-            if (STATS) {
-                cs[j] += v;
-                cq[j] = fmaf(v, v, cq[j]);
+            if (STATS) {   // ragged tile: only stored values reach this point; the shift is the first of them
+                st.add(j, v, (st.first >> j) & 1u);
+                st.first &= ~(1u << j);
             }
             if (p.out_nchw)
                 p.y[((int64_t)nb * p.Cout + n) * p.ohw + (m - nb * p.ohw)] = v;
@@ -194,8 +227,8 @@ __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&a
 template <int NT>
 __device__ __forceinline__ void split_epilogue(const SplitP& p, const f32x16 (&acc)[NT], int m0, int n0, int wave, int lrow,
                                                int half, int tile_rows = SBM) {
-    float cs[NT], cq[NT];
-    split_epilogue<NT, false>(p, acc, m0, n0, wave, lrow, half, tile_rows, cs, cq);
+    StatAcc<NT> st;
+    split_epilogue<NT, false>(p, acc, m0, n0, wave, lrow, half, tile_rows, st);
 }
 
 // Column sums of one block tile -> p.stats.  Lanes l and l+32 hold the two row halves of a column, the four waves the row
@@ -409,16 +442,13 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(SplitP p) {
     }
 
     if (p.stats) {
-        float cs[NT], cq[NT];
+        StatAcc<NT> st;
         double ds[NT], dq[NT];
+        st.clear();
 #pragma unroll
-        for (int j = 0; j < NT; ++j) cs[j] = cq[j] = 0.f;
-        split_epilogue<NT, true>(p, acc, m0, n0, wave, lrow, half, SBM, cs, cq);
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            ds[j] = (double)cs[j];
-            dq[j] = (double)cq[j];
-        }
+        for (int j = 0; j < NT; ++j) ds[j] = dq[j] = 0.0;
+        split_epilogue<NT, true>(p, acc, m0, n0, wave, lrow, half, SBM, st);
+        st.flush(ds, dq);
         stats_reduce<NT>(p, ds, dq, lds, m0, n0, SBM, tid, wave, lrow, half);
         return;
     }
@@ -703,24 +733,20 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         for (int r = 0; r < RB; ++r) split_epilogue<NT>(q, acc[r], m0, n0, wave * RB + r, lrow, half, SBM * RB);
         return;
     }
-    if (p.stats) {
-        // fp32 partials cover ONE 32-row block (16 rows per lane) whatever the tile structure, everything above is fp64:
-        // the statistics do not depend on the 128 / 256-row choice beyond fp64 rounding
+    // (the 128-row kernels with 4 or 5 column tiles run two workgroups per CU at 256 registers each and have none to spare:
+    // the statistics epilogue would spill values that live across the k-loop, so those keep the standalone pass)
+    constexpr bool STATS_OK = RB == 2 || NT <= 3;
+    if (STATS_OK && p.stats) {
+        // one shifted fp32 partial per lane and column over its 16 * RB rows (the fp64 conversion after the last store keeps
+        // the register pressure of the epilogue where it was: anything more spills values that live across the k-loop)
+        StatAcc<NT> st;
+        st.clear();
+#pragma unroll
+        for (int r = 0; r < RB; ++r) split_epilogue<NT, true>(p, acc[r], m0, n0, wave * RB + r, lrow, half, SBM * RB, st, r == 0);
         double ds[NT], dq[NT];
 #pragma unroll
         for (int j = 0; j < NT; ++j) ds[j] = dq[j] = 0.0;
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            float cs[NT], cq[NT];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) cs[j] = cq[j] = 0.f;
-            split_epilogue<NT, true>(p, acc[r], m0, n0, wave * RB + r, lrow, half, SBM * RB, cs, cq);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                ds[j] += (double)cs[j];
-                dq[j] += (double)cq[j];
-            }
-        }
+        st.flush(ds, dq);
         stats_reduce<NT>(p, ds, dq, Bs, m0, n0, SBM * RB, tid, wave, lrow, half);
         return;
     }
@@ -928,7 +954,7 @@ void conv2d_split(const ConvArgs& a, int nt, int ksplit, int ad, hipStream_t s) 
     p.stats_chunks = 0;
     if (a.stats) {
         const int rows = ad == 2 ? 2 * SBM : SBM;
-        DSD_CHECK(p.ksplit == 1 && !a.out_nchw && p.ohw % rows == 0 && p.ohw / rows == a.stats_chunks,
+        DSD_CHECK(p.ksplit == 1 && !a.out_nchw && p.ohw % rows == 0 && p.ohw / rows == a.stats_chunks && !(ad == 1 && nt >= 4),
                   "conv2d: output statistics requested with %d chunks but the kernel (tile %d rows, split-K x%d, ohw %d) cannot "
                   "emit them (conv2d_stats_chunks)", a.stats_chunks, rows, p.ksplit, p.ohw);
         p.stats = a.stats;

@@ -26,6 +26,7 @@ struct ConvArgs {
     int variant = -1;           // kernel variant override (-1 = default / env DSD_CONV_VARIANT)
     int precision = 0;          // PREC_F32 | PREC_BF16X3 | PREC_BF16X6 (conv_split.hip)
     const void* w_split = nullptr;  // [3][Cout][ks*ks*Cin] bf16 pieces of w (needed for the split precisions)
+    const void* w_wino = nullptr;   // transformed + split + packed weights of the F(2,3) kernel (conv_wino.hip), optional
     int* ovf = nullptr;             // device flag set by the f16x3 kernels when an operand exceeds the fp16 range
     float* scratch = nullptr;       // split-K partial sums (conv2d_scratch_bytes() bytes); without it small grids run unsplit
     size_t scratch_bytes = 0;
@@ -60,6 +61,13 @@ void conv2d_split_plan(const ConvArgs& a, int nt_default, int* nt, int* ksplit, 
 const char* conv2d_variant(const ConvArgs& a);
 void conv2d_plan_query(const ConvArgs& a, int* structure, int* nt, int* ksplit);   // what conv2d() would launch   // name of the kernel conv2d() will launch for these arguments
 void pack_ohwi(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, hipStream_t s);
+// conv_wino.hip: 3x3 stride-1 convolution as F(2,3) along the width (1.5x fewer MFMAs), bf16x6 arithmetic
+bool conv2d_wino_shape_ok(const ConvArgs& a);      // could run there if it had packed weights
+bool conv2d_wino_eligible(const ConvArgs& a);      // shape_ok and a.w_wino present
+size_t wino_packed_bytes(int Cout, int Cin);
+void wino_pack_weights(const float* w_ohwi, int Cout, int Cin, void* packed, hipStream_t s);
+void conv2d_wino(const ConvArgs& a, hipStream_t s);
+int conv2d_wino_stats_chunks(const ConvArgs& a);
 
 // ---------------------------------------------------------------- norm.hip
 int gn_nchunks(int HW, int C);

@@ -463,7 +463,7 @@ void dsd::net_set_param(dsd_handle* h, const char* name, const float* src, const
     if (!h->param_ev) DSD_HIP(hipEventCreateWithFlags(&h->param_ev, hipEventDisableTiming));
     DSD_HIP(hipEventRecord(h->param_ev, s));
     const std::string conv_name = p.name.size() > 7 ? p.name.substr(0, p.name.size() - 7) : p.name;   // "<conv>.weight" -> "<conv>"
-    for (const std::string& key : {conv_name, conv_name + "#f16"}) {
+    for (const std::string& key : {conv_name, conv_name + "#f16", conv_name + "#wino"}) {
         auto sp = h->wsplit.find(key);
         if (sp != h->wsplit.end()) {
             DSD_HIP(hipDeviceSynchronize());
@@ -632,6 +632,21 @@ struct Builder {
             a.w_split = it->second;
             a.precision = hd->precision;
             a.ovf = f16 ? hd->ovf : nullptr;
+            // 3x3 stride-1 layers with enough tiles: F(2,3)-along-W kernel (conv_wino.hip), transformed weights packed once
+            if (hd->use_winograd && conv2d_wino_shape_ok(a)) {
+                const std::string wkey = name + "#wino";
+                auto wi = hd->wsplit.find(wkey);
+                if (wi == hd->wsplit.end()) {
+                    void* packed = nullptr;
+                    const size_t wb = wino_packed_bytes(cout, x.c);
+                    DSD_HIP(hipMalloc(&packed, wb));
+                    wino_pack_weights(a.w, cout, x.c, packed, ps);
+                    split_any = true;
+                    wi = hd->wsplit.emplace(wkey, packed).first;
+                    hd->wsplit_bytes[wkey] = wb;
+                }
+                a.w_wino = wi->second;
+            }
         }
         const size_t skb = conv2d_scratch_bytes(a);            // split-K partial tiles of the small-grid layers
         const size_t skoff = skb ? alloc_raw(skb) : 0;

@@ -22,7 +22,7 @@ def to_nchw(x: torch.Tensor) -> torch.Tensor:
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
 
 
-STRUCTURES = {"auto": 0, "adirect": 16, "staged": 32, "adirect256": 64}
+STRUCTURES = {"auto": 0, "adirect": 16, "staged": 32, "adirect256": 64, "winograd": 128}
 
 
 def conv2d(x_nhwc, w_oihw, bias, stride=1, upsample=False, emb=None, res=None, precision="f32", structure="auto"):

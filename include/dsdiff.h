@@ -106,6 +106,13 @@ int dsd_set_share_zero_streams(dsd_handle* h, int on);
  * in the epilogue of the kernel that writes the tensor and the separate statistics pass over HBM disappears
  * (openaimodel.py:264-284: "fused GroupNorm" of the north star).  0 = always run the standalone pass (A/B, tests). */
 int dsd_set_fuse_gn_stats(dsd_handle* h, int on);
+/* bf16x6 mode only (ON by default): 3x3 stride-1 convolutions with >= 4096 output pixels, an even width, Cin % 16 == 0 and
+ * Cout % 32 == 0 run as Winograd F(2,3) ALONG THE WIDTH — 4 instead of 6 products per pair of outputs and filter row,
+ * i.e. 1.5x fewer MFMAs.  The input transform (sums / differences of neighbouring pixels) is done in fp32, the weight
+ * transform once in fp64, and both operands are then split into three bf16 pieces exactly as in the direct kernel, so
+ * every operand still carries 24 significant bits; the result differs from the direct form by an fp32 re-association of
+ * the convolution sum (measured, tests/test_ops_gpu.py).  0 = the direct kernels everywhere. */
+int dsd_set_winograd(dsd_handle* h, int on);
 /* 0 if every parameter has been set, else -1 with the first missing name in dsd_last_error(). */
 int dsd_params_ready(dsd_handle* h);
 
@@ -258,14 +265,15 @@ int dsd_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w_o
 /* Same with an explicit arithmetic mode: 0 = fp32 MFMA, 1 = bf16x3, 2 = bf16x6 (fp32 operands split into bf16 pieces,
  * fp32 accumulation; conv_split.hip).  Shapes the split kernel cannot take fall back to fp32.  OR-ing 16 / 32 / 64
  * into `precision` forces the A-direct / fully staged / 256-row A-direct kernel structure (tests); otherwise the library
- * chooses. */
+ * chooses; OR-ing 128 (with precision 2) runs the F(2,3) kernel of dsd_set_winograd and fails if the shape cannot take it. */
 int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout,
                        int ks, int stride, int upsample, const float* emb, const float* res, int precision, float* y,
                        void* stream);
 /* Micro-benchmark of the convolution kernel on random data (library-owned buffers): average ms per launch over
  * `iters` back-to-back launches (hipEvents) and the algorithmic FLOPs of one launch.  variant: -1/0 default fp32
  * kernel, 1 flat-load fp32 kernel, 10 bf16x3, 11 bf16x6, 12 f16x3 (library's choice of structure), 20/21 both operands staged
- * through LDS, 30/31 activations read straight into registers (128-row tile), 40/41/42 the same on the 256-row tile. */
+ * through LDS, 30/31 activations read straight into registers (128-row tile), 40/41/42 the same on the 256-row tile,
+ * 50 bf16x6 as F(2,3) along the width (FLOPs reported are those of the direct form: "fp32-equivalent"). */
 int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride, int variant, int iters, float* avg_ms,
                      double* flops);
 /* How the library would run a convolution (host-side query, no GPU work): kernel structure (0 both operands staged

@@ -104,6 +104,51 @@ def test_conv2d_split_structures(ops, prec, structure):
         assert rel_l2(ops.to_nchw(y), ref) < PREC_TOL[prec], (case, prec, structure)
 
 
+WINO_CASES = [
+    # N, H, W, Cin, Cout        (3x3, stride 1; >= 4096 output pixels, even W, Cin % 32 == 0, Cout = 0 or 64 mod 128)
+    (1, 64, 64, 64, 128),        # one full N tile
+    (2, 32, 64, 32, 320),        # 128 + 128 + 64: the narrow last N tile; non-square
+    (1, 64, 64, 96, 64),         # a single narrow tile, 18 k-tiles
+    (3, 40, 36, 64, 192),        # ragged last M tile (4320 pixels = 16.9 block tiles), W/2 = 18 tiles per row
+    (16, 16, 16, 320, 960),      # a 16x16 layer of the network at batch 16 (7 full N tiles + 1 narrow)
+]
+
+
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv2d_winograd_f23(ops, case):
+    """conv_wino.hip (F(2,3) along the width, bf16x6 operands) against float64, with and without the epilogue fusions, next to
+    the direct bf16x6 kernel on the same data: same tolerance (2e-6), and the printed ratio shows what the fp32 input /
+    output transforms cost in accuracy."""
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case) + 3)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xc, wc, bc = cu(ops.to_nhwc(x)), cu(w), cu(b)
+    yw = ops.conv2d(xc, wc, bc, precision="bf16x6", structure="winograd")
+    yd = ops.conv2d(xc, wc, bc, precision="bf16x6")
+    ew, ed = rel_l2(ops.to_nchw(yw), ref), rel_l2(ops.to_nchw(yd), ref)
+    print(f"winograd F(2,3) {case}: rel-L2 vs fp64 {ew:.3e} (direct bf16x6: {ed:.3e}, ratio {ew / ed:.2f})")
+    assert ew < PREC_TOL["bf16x6"]
+    emb = torch.randn(N, Cout, generator=g)
+    res = torch.randn(*ref.shape, generator=g)
+    ref2 = ref + emb.double()[:, :, None, None] + res.double()
+    y2 = ops.conv2d(xc, wc, bc, emb=cu(emb), res=cu(ops.to_nhwc(res)), precision="bf16x6", structure="winograd")
+    assert rel_l2(ops.to_nchw(y2), ref2) < PREC_TOL["bf16x6"]
+    assert torch.equal(y2, ops.conv2d(xc, wc, bc, emb=cu(emb), res=cu(ops.to_nhwc(res)), precision="bf16x6", structure="winograd"))
+
+
+def test_conv2d_winograd_rejects_ineligible(ops):
+    from diffusion_models_dsdiff_amd import _lib
+    g = torch.Generator().manual_seed(1)
+    for shp, cout, stride in (((1, 64, 16, 16), 128, 1), ((1, 64, 64, 63), 128, 1), ((1, 64, 64, 64), 96, 1), ((1, 64, 64, 64), 128, 2)):
+        x = torch.randn(*shp, generator=g)
+        w = torch.randn(cout, shp[1], 3, 3, generator=g)
+        with pytest.raises(_lib.DsdError):
+            ops.conv2d(cu(ops.to_nhwc(x)), cu(w), cu(torch.zeros(cout)), stride=stride, precision="bf16x6", structure="winograd")
+
+
 def test_conv2d_split_extreme_magnitudes(ops):
     """bf16 pieces keep fp32's exponent range: tiny and huge operands, exact zeros, and denormal-scale residuals."""
     g = torch.Generator().manual_seed(3)
