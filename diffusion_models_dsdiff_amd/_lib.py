@@ -19,7 +19,8 @@ MODE_A_DDPM, MODE_A_DDIM, MODE_B_DDPM, MODE_B_DDIM = 0, 1, 2, 3
 PRED_EPS, PRED_X0, PRED_V = 0, 1, 2
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
 (BLOCK_RES, BLOCK_ATTN, BLOCK_UPSAMPLE, BLOCK_DOWNSAMPLE, BLOCK_DISENTANGLE, BLOCK_SE, BLOCK_CROSSATTN,
- BLOCK_FF_GEGLU, BLOCK_BASIC_TRANSFORMER, BLOCK_SPATIAL_TRANSFORMER, BLOCK_VAE_ENCODER, BLOCK_VAE_DECODER) = range(12)
+ BLOCK_FF_GEGLU, BLOCK_BASIC_TRANSFORMER, BLOCK_SPATIAL_TRANSFORMER, BLOCK_VAE_ENCODER, BLOCK_VAE_DECODER,
+ BLOCK_DIT) = range(13)
 
 # every symbol include/dsdiff.h declares (tests/test_abi.py checks the header against this list)
 EXPORTS = [

@@ -60,6 +60,7 @@ struct WinoP {
     unsigned x_bytes;
     double* stats;
     int stats_chunks;
+    int whatif;   // experiments (env DSD_WINO_WHATIF): 1 = no activation loads in the k-loop, 2 = no weight DMA, 4 = no transform/split
 };
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
@@ -216,7 +217,7 @@ __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
 #define DSD_WINO_TILE(KT_, SO, CUR, OTH)                                                                                     \
     {                                                                                                                        \
         __syncthreads(); /* DMA of this tile has landed (vmcnt(0) before the barrier); every wave left the other stage */    \
-        if ((KT_) + 1 < p.KT) dma_tile((KT_) + 1, WSTAGE - (SO));                                                            \
+        if ((KT_) + 1 < p.KT && !(p.whatif & 2)) dma_tile((KT_) + 1, WSTAGE - (SO));                                         \
         const unsigned char* bf = Bs + (SO) + frag_off;                                                                      \
         bf16x8 b_cur[3], b_nxt[3];                                                                                           \
         _Pragma("unroll") for (int q = 0; q < 3; ++q) b_nxt[q] = b_cur[q] = *reinterpret_cast<const bf16x8*>(bf + (q * 4) * WPLANE); \
@@ -229,14 +230,16 @@ __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
                     b_nxt[q] = *reinterpret_cast<const bf16x8*>(bf + (q * 4 + pos1) * WPLANE + j1 * 32 * 32);                \
             }                                                                                                                \
             __builtin_amdgcn_sched_barrier(0);                                                                               \
-            if (u == 0) split8x3(raw[OTH][3][0], raw[OTH][3][1], af[3]);                                                     \
-            if (u == 2 * NT) {                                                                                               \
-                transform(CUR);                                                                                              \
-                split8x3(raw[CUR][0][0], raw[CUR][0][1], af[0]);                                                             \
+            if (!(p.whatif & 4)) {                                                                                           \
+                if (u == 0) split8x3(raw[OTH][3][0], raw[OTH][3][1], af[3]);                                                 \
+                if (u == 2 * NT) {                                                                                           \
+                    transform(CUR);                                                                                          \
+                    split8x3(raw[CUR][0][0], raw[CUR][0][1], af[0]);                                                         \
+                }                                                                                                            \
+                if (u == 2 * NT + 1) split8x3(raw[CUR][1][0], raw[CUR][1][1], af[1]);                                        \
+                if (u == 3 * NT) split8x3(raw[CUR][2][0], raw[CUR][2][1], af[2]);                                            \
             }                                                                                                                \
-            if (u == 2 * NT + 1) split8x3(raw[CUR][1][0], raw[CUR][1][1], af[1]);                                            \
-            if (u == 2 * NT + 2) load_raw(OTH, (KT_) + 2);                                                                   \
-            if (u == 3 * NT) split8x3(raw[CUR][2][0], raw[CUR][2][1], af[2]);                                                \
+            if (u == 2 * NT + 2 && !(p.whatif & 1)) load_raw(OTH, (KT_) + 2);                                                \
             mfma6(af[pos], b_cur, acc[pos][j]);                                                                              \
             _Pragma("unroll") for (int q = 0; q < 3; ++q) b_cur[q] = b_nxt[q];                                               \
             __builtin_amdgcn_sched_barrier(0);                                                                               \
@@ -417,6 +420,8 @@ void conv2d_wino(const ConvArgs& a, hipStream_t s) {
     p.tiles_m = cdiv(p.T, WTILES);
     p.tiles_n = cdiv(a.Cout, WBROWS);
     p.x_bytes = (unsigned)(((int64_t)(a.N - 1) * p.x_bs + (int64_t)a.H * a.W * a.Cin) * 4);
+    static const int whatif = getenv("DSD_WINO_WHATIF") ? atoi(getenv("DSD_WINO_WHATIF")) : 0;
+    p.whatif = whatif;
     p.stats = nullptr;
     if (a.stats) {
         DSD_CHECK(p.ohw % (2 * WTILES) == 0 && p.ohw / (2 * WTILES) == a.stats_chunks,

@@ -119,6 +119,23 @@ void nhwc_to_nchw(const float* x, int N, int C, int HW, float* y, hipStream_t s)
 void avgpool2(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);
 void upsample2(const float* x, int N, int H, int W, int C, float* y, hipStream_t s);
 void geglu(const float* x, int64_t rows, int inner, float* y, hipStream_t s);
+// ---- DiT pieces (UNet_DS_Diff/DiT_models.py)
+// LayerNorm without affine (eps) then modulate: y[n,t,:] = ((x - mean) * rstd) * (1 + scale[n,:]) + shift[n,:]; mod rows have
+// stride mod_stride, shift at +shift_off, scale at +scale_off   (DiTBlock.forward :119-121, FinalLayer.forward :139-141)
+void ln_modulate(const float* x, int N, int T, int C, const float* mod, int mod_stride, int shift_off, int scale_off, float eps,
+                 float* y, hipStream_t s);
+// x[n,t,:] += gate[n,:] * y[n,t,:]   (gate = mod + gate_off, the adaLN-Zero residual :120-121); in place on x
+void gated_residual(float* x, const float* y, int N, int T, int C, const float* mod, int mod_stride, int gate_off, hipStream_t s);
+// in place: GELU(approximate="tanh")
+void gelu_tanh(float* x, int64_t n, hipStream_t s);
+// x [N,C,H,W] -> tokens [N, (H/p)*(W/p), C*p*p] in Conv2d weight order (c, ph, pw)   (timm PatchEmbed = Conv2d(k = stride = p))
+void patchify(const float* x, int N, int C, int H, int W, int p, float* y, hipStream_t s);
+// tokens [N, h*w, p*p*c] (order ph, pw, c) -> [N, c, h*p, w*p]   (DiT.unpatchify :209-222)
+void unpatchify(const float* x, int N, int c, int h, int w, int p, float* y, hipStream_t s);
+// x[n,t,:] += pos[t,:]
+void add_rows_broadcast(float* x, const float* pos, int N, int64_t TC, hipStream_t s);
+// y[n,:] = (a ? a[n,:] : 0) + table[idx[n], :]   (LabelEmbedder: c = t_emb + y_emb :241-244); idx int64 on device
+void embed_add(const float* a, const float* table, const long long* idx, int N, int C, float* y, hipStream_t s);
 // in place: s[r][:] = softmax(s[r][:] * scale) over `cols` contiguous fp32 (one workgroup per row; max-subtracted, fp32)
 void softmax_rows(float* s, int64_t rows, int cols, float scale, hipStream_t st);
 void add2(const float* a, const float* b, int64_t n, float* y, hipStream_t s);

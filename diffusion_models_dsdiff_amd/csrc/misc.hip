@@ -293,6 +293,135 @@ void softmax_rows(float* s, int64_t rows, int cols, float scale, hipStream_t st)
     check_launch("softmax_rows");
 }
 
+// ------------------------------------------------------------------------------------------------ DiT (DiT_models.py)
+// one wave per token row: two-pass LayerNorm (mean, then centred variance) in fp32, no affine, then adaLN modulate
+__global__ __launch_bounds__(256) void ln_modulate_kernel(const float* __restrict__ x, int64_t rows, int T, int C,
+                                                          const float* __restrict__ mod, int mod_stride, int shift_off,
+                                                          int scale_off, float eps, float* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    const float* mr = mod + (row / T) * mod_stride;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float d = xr[c] - mean;
+        q = fmaf(d, d, q);
+    }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.f / sqrtf(q / C + eps);
+    for (int c = lane; c < C; c += 64)
+        y[row * C + c] = ((xr[c] - mean) * rstd) * (1.f + mr[scale_off + c]) + mr[shift_off + c];
+}
+void ln_modulate(const float* x, int N, int T, int C, const float* mod, int mod_stride, int shift_off, int scale_off, float eps,
+                 float* y, hipStream_t s) {
+    const int64_t rows = (int64_t)N * T;
+    if (rows == 0) return;
+    hipLaunchKernelGGL(ln_modulate_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, s, x, rows, T, C, mod, mod_stride, shift_off, scale_off,
+                       eps, y);
+    check_launch("ln_modulate");
+}
+
+__global__ void gated_residual_kernel(float4* __restrict__ x, const float4* __restrict__ y, int64_t total4, int64_t tc4, int c4,
+                                      const float* __restrict__ mod, int mod_stride, int gate_off) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int64_t n = i / tc4;
+        const int c = (int)(i % c4) * 4;
+        const float4 g = *reinterpret_cast<const float4*>(mod + n * mod_stride + gate_off + c);
+        float4 a = x[i];
+        const float4 b = y[i];
+        a.x = fmaf(g.x, b.x, a.x); a.y = fmaf(g.y, b.y, a.y); a.z = fmaf(g.z, b.z, a.z); a.w = fmaf(g.w, b.w, a.w);
+        x[i] = a;
+    }
+}
+void gated_residual(float* x, const float* y, int N, int T, int C, const float* mod, int mod_stride, int gate_off, hipStream_t s) {
+    DSD_CHECK(C % 4 == 0 && mod_stride % 4 == 0 && gate_off % 4 == 0, "gated_residual: widths must be multiples of 4");
+    const int64_t total4 = (int64_t)N * T * C / 4;
+    if (!total4) return;
+    hipLaunchKernelGGL(gated_residual_kernel, dim3((unsigned)std::min<int64_t>((total4 + 255) / 256, 65535)), dim3(256), 0, s, (float4*)x,
+                       (const float4*)y, total4, (int64_t)T * C / 4, C / 4, mod, mod_stride, gate_off);
+    check_launch("gated_residual");
+}
+
+// torch's tanh approximation: 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+__global__ void gelu_tanh_kernel(float* __restrict__ x, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float v = x[i];
+        const float inner = 0.7978845608028654f * (v + 0.044715f * v * v * v);
+        x[i] = 0.5f * v * (1.f + tanhf(inner));
+    }
+}
+void gelu_tanh(float* x, int64_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(gelu_tanh_kernel, dim3((unsigned)std::min<int64_t>((n + 255) / 256, 65535)), dim3(256), 0, s, x, n);
+    check_launch("gelu_tanh");
+}
+
+__global__ void patchify_kernel(const float* __restrict__ x, int C, int H, int W, int p, int64_t total, float* __restrict__ y) {
+    const int h = H / p, w = W / p, K = C * p * p;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int k = (int)(i % K);
+        int64_t r = i / K;
+        const int tw = (int)(r % w); r /= w;
+        const int th = (int)(r % h);
+        const int64_t n = r / h;
+        const int pw = k % p, ph = (k / p) % p, c = k / (p * p);
+        y[i] = x[((n * C + c) * H + th * p + ph) * W + tw * p + pw];
+    }
+}
+void patchify(const float* x, int N, int C, int H, int W, int p, float* y, hipStream_t s) {
+    const int64_t total = (int64_t)N * C * H * W;
+    if (!total) return;
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65535)), dim3(256), 0, s, x, C, H, W, p, total, y);
+    check_launch("patchify");
+}
+
+__global__ void unpatchify_kernel(const float* __restrict__ x, int c, int h, int w, int p, int64_t total, float* __restrict__ y) {
+    const int Hh = h * p, Ww = w * p;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {   // i over the output NCHW
+        const int ow = (int)(i % Ww);
+        int64_t r = i / Ww;
+        const int oh = (int)(r % Hh); r /= Hh;
+        const int ch = (int)(r % c);
+        const int64_t n = r / c;
+        const int th = oh / p, ph = oh - th * p, tw = ow / p, pw = ow - tw * p;
+        y[i] = x[((n * h + th) * w + tw) * (int64_t)(p * p * c) + (ph * p + pw) * c + ch];
+    }
+}
+void unpatchify(const float* x, int N, int c, int h, int w, int p, float* y, hipStream_t s) {
+    const int64_t total = (int64_t)N * c * h * p * w * p;
+    if (!total) return;
+    hipLaunchKernelGGL(unpatchify_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65535)), dim3(256), 0, s, x, c, h, w, p, total, y);
+    check_launch("unpatchify");
+}
+
+__global__ void add_rows_broadcast_kernel(float* __restrict__ x, const float* __restrict__ pos, int64_t total, int64_t tc) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) x[i] += pos[i % tc];
+}
+void add_rows_broadcast(float* x, const float* pos, int N, int64_t TC, hipStream_t s) {
+    const int64_t total = (int64_t)N * TC;
+    if (!total) return;
+    hipLaunchKernelGGL(add_rows_broadcast_kernel, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 65535)), dim3(256), 0, s, x, pos, total, TC);
+    check_launch("add_rows_broadcast");
+}
+
+__global__ void embed_add_kernel(const float* __restrict__ a, const float* __restrict__ table, const long long* __restrict__ idx, int N,
+                                 int C, float* __restrict__ y) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * C) return;
+    const int n = i / C, c = i - n * C;
+    y[i] = (a ? a[i] : 0.f) + table[idx[n] * C + c];
+}
+void embed_add(const float* a, const float* table, const long long* idx, int N, int C, float* y, hipStream_t s) {
+    if (N * C == 0) return;
+    hipLaunchKernelGGL(embed_add_kernel, dim3(cdiv(N * C, 256)), dim3(256), 0, s, a, table, idx, N, C, y);
+    check_launch("embed_add");
+}
+
 __global__ void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float* __restrict__ y) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = a[i] + b[i];
 }

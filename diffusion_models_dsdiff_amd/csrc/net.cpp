@@ -268,6 +268,40 @@ VaeCfg vae_cfg(const std::vector<int32_t>& a) {
     DSD_CHECK(c.nrb >= 1 && c.z >= 1 && c.in_ch >= 1 && c.out_ch >= 1 && c.embed >= 1, "VAE: bad configuration");
     return c;
 }
+// ---- DiT (UNet_DS_Diff/DiT_models.py:145-262).  iargs: input_size, patch_size, in_channels, hidden_size, depth, num_heads,
+//      mlp_hidden (= int(hidden_size * mlp_ratio)), num_classes, learn_sigma, use_cfg_embedding (class_dropout_prob > 0)
+struct DitCfg {
+    int input, p, cin, D, depth, heads, mlp, classes, learn_sigma, cfg_emb;
+    int cout() const { return learn_sigma ? cin / 3 * 2 : cin; }   // DiT.__init__ :163 (sic)
+    int T() const { return (input / p) * (input / p); }
+};
+DitCfg dit_cfg(const std::vector<int32_t>& a) {
+    DSD_CHECK(a.size() >= 10, "DiT handle needs 10 integer arguments");
+    DitCfg c{a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], a[8], a[9]};
+    DSD_CHECK(c.p >= 1 && c.input % c.p == 0 && c.D % c.heads == 0 && (c.D / c.heads) % 4 == 0 && c.D / c.heads <= 128 && c.D % 4 == 0,
+              "DiT: unsupported geometry (input %d, patch %d, hidden %d, heads %d)", c.input, c.p, c.D, c.heads);
+    DSD_CHECK(c.depth >= 1 && c.cout() >= 1 && c.mlp % 4 == 0, "DiT: bad configuration");
+    return c;
+}
+void p_dit(dsd_handle* h, const DitCfg& c) {
+    add_param(h, "x_embedder.proj.weight", {c.D, c.cin, c.p, c.p});
+    add_param(h, "x_embedder.proj.bias", {c.D});
+    p_lin(h, "t_embedder.mlp.0", 256, c.D);
+    p_lin(h, "t_embedder.mlp.2", c.D, c.D);
+    if (c.classes > 0) add_param(h, "y_embedder.embedding_table.weight", {c.classes + (c.cfg_emb ? 1 : 0), c.D});
+    add_param(h, "pos_embed", {1, c.T(), c.D});
+    for (int i = 0; i < c.depth; ++i) {
+        const std::string b = "blocks." + std::to_string(i);
+        p_lin(h, b + ".attn.qkv", c.D, 3 * c.D);
+        p_lin(h, b + ".attn.proj", c.D, c.D);
+        p_lin(h, b + ".mlp.fc1", c.D, c.mlp);
+        p_lin(h, b + ".mlp.fc2", c.mlp, c.D);
+        p_lin(h, b + ".adaLN_modulation.1", c.D, 6 * c.D, true, /*wregion=*/1);   // all modulations = one GEMM per forward
+    }
+    p_lin(h, "final_layer.linear", c.D, c.p * c.p * c.cout());
+    p_lin(h, "final_layer.adaLN_modulation.1", c.D, 2 * c.D, true, 1);
+}
+
 void p_vae_res(dsd_handle* h, const std::string& p, int cin, int cout) {
     p_norm(h, p + ".norm1", cin);
     p_conv(h, p + ".conv1", cin, cout, 3);
@@ -392,6 +426,7 @@ void dsd::net_declare_params(dsd_handle* h) {
                 if (a[5]) p_lin(h, "proj_out", a[0], inner); else p_conv(h, "proj_out", inner, a[0], 1);
                 break;
             }
+            case DSD_BLOCK_DIT: p_dit(h, dit_cfg(a)); break;
             case DSD_BLOCK_VAE_ENCODER: p_vae_encoder(h, vae_cfg(a)); break;
             case DSD_BLOCK_VAE_DECODER: p_vae_decoder(h, vae_cfg(a)); break;
             default: fail("unknown block kind %d", h->block_kind);
@@ -1305,6 +1340,139 @@ void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats, bool 
     b.release(emb_all);
 }
 
+// --------------------------------------------------------------------------------- DiT.forward (DiT_models.py:224-243)
+// x: NCHW [B, in_channels, S, S] (the caller concatenates `cond`), aux = t [B] fp32, aux2 = y [B] int64 (optional).
+void build_dit(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
+    dsd_handle* hd = b.hd;
+    const DitCfg c = dit_cfg(hd->iargs);
+    const int B = b.B, T = c.T(), D = c.D, p = c.p, K = c.cin * p * p;
+    DSD_CHECK(C == c.cin, "DiT: input has %d channels, x_embedder expects %d (x and cond concatenated)", C, c.cin);
+    DSD_CHECK(H == c.input && W == c.input, "DiT: input is %dx%d, pos_embed was built for %dx%d", H, W, c.input, c.input);
+    DSD_CHECK(aux_len == 1, "DiT: timesteps missing");
+    DSD_CHECK(aux_len2 == 0 || c.classes > 0, "DiT: labels given but the model has no label embedding");
+    const int etot = (int)hd->emb_total;   // depth * 6D + 2D: every adaLN modulation of the forward
+    // ---- patch embedding: Conv2d(k = stride = p) = patch gather + GEMM, + bias, + fixed sin-cos position table (:232)
+    Tn tok = b.alloc(B, T, 1, K);
+    {
+        const size_t to = tok.off;
+        b.op([=](hipStream_t s) { patchify(hd->io.x_nchw, B, C, H, W, p, reinterpret_cast<float*>(hd->arena + to), s); }, 1, "patchify");
+    }
+    Tn x = b.conv("x_embedder.proj", tok, D, 1);
+    b.release(tok);
+    {
+        const size_t xo = x.off;
+        const float* pos = b.W("pos_embed");
+        b.op([=](hipStream_t s) { add_rows_broadcast(reinterpret_cast<float*>(hd->arena + xo), pos, B, (int64_t)T * D, s); }, 1, "pos_embed_add");
+    }
+    // ---- conditioning vector c = t_embedder(t) [+ y_embedder(y)] and ALL adaLN modulations as one GEMM (:233-238, :113-116)
+    Tn tf = b.alloc(B, 1, 1, 256), e1 = b.alloc(B, 1, 1, D), cvec = b.alloc(B, 1, 1, D), mod = b.alloc(B, 1, 1, etot);
+    {
+        const size_t tfo = tf.off, e1o = e1.off, co = cvec.off, mo = mod.off;
+        const float *w0 = b.W("t_embedder.mlp.0.weight"), *b0 = b.W("t_embedder.mlp.0.bias");
+        const float *w2 = b.W("t_embedder.mlp.2.weight"), *b2 = b.W("t_embedder.mlp.2.bias");
+        const float* table = c.classes > 0 ? b.W("y_embedder.embedding_table.weight") : nullptr;
+        const float* wall = reinterpret_cast<const float*>(hd->slab + hd->emb_w_off);
+        const float* ball = reinterpret_cast<const float*>(hd->slab + hd->emb_b_off);
+        const bool labels = aux_len2 > 0;
+        const double fl = 2.0 * B * (256.0 * D + (double)D * D + (double)D * etot);
+        b.plan.flops += fl;
+        b.op([=](hipStream_t s) {
+            float* tfp = reinterpret_cast<float*>(hd->arena + tfo);
+            float* e1p = reinterpret_cast<float*>(hd->arena + e1o);
+            float* cp = reinterpret_cast<float*>(hd->arena + co);
+            float* mp = reinterpret_cast<float*>(hd->arena + mo);
+            timestep_embedding(hd->io.aux, 1, B, 256, tfp, s, hd->freqs);
+            linear(tfp, B, 256, 256, w0, b0, D, ACT_NONE, e1p, D, s);
+            linear(e1p, B, D, D, w2, b2, D, ACT_SILU, cp, D, s);
+            if (labels) embed_add(cp, table, reinterpret_cast<const long long*>(hd->io.aux2), B, D, cp, s);
+            linear(cp, B, D, D, wall, ball, etot, ACT_SILU, mp, etot, s);
+        }, 5, "dit_conditioning", fl);
+    }
+    b.release(tf); b.release(e1); b.release(cvec);
+    // column of each modulation inside `mod` = position of its bias in the contiguous bias region (declaration order)
+    std::unordered_map<std::string, int> col;
+    {
+        int cc = 0;
+        for (const auto& pr : hd->params)
+            if (pr.region == 2) {
+                col[pr.name.substr(0, pr.name.size() - std::strlen(".bias"))] = cc;
+                cc += (int)pr.numel;
+            }
+    }
+    auto ln_mod = [&](const Tn& src, int mcol, int shift_off, int scale_off) {
+        Tn y = b.alloc(src.n, src.h, src.w, src.c);
+        const size_t so = src.off, yo = y.off, mo = mod.off;
+        b.op([=](hipStream_t s) {
+            ln_modulate(reinterpret_cast<const float*>(hd->arena + so), B, T, D, reinterpret_cast<const float*>(hd->arena + mo) + mcol, etot,
+                        shift_off, scale_off, 1e-6f, reinterpret_cast<float*>(hd->arena + yo), s);
+        }, 1, "ln_modulate", 0.0, 8.0 * B * T * D);
+        return y;
+    };
+    auto gated = [&](const Tn& xx, const Tn& yy, int mcol, int gate_off) {
+        const size_t xo = xx.off, yo = yy.off, mo = mod.off;
+        b.op([=](hipStream_t s) {
+            gated_residual(reinterpret_cast<float*>(hd->arena + xo), reinterpret_cast<const float*>(hd->arena + yo), B, T, D,
+                           reinterpret_cast<const float*>(hd->arena + mo) + mcol, etot, gate_off, s);
+        }, 1, "gated_residual", 0.0, 12.0 * B * T * D);
+    };
+    const int hdim = D / c.heads;
+    for (int i = 0; i < c.depth; ++i) {   // DiTBlock.forward :118-122
+        const std::string bp = "blocks." + std::to_string(i);
+        const int mc = col.at(bp + ".adaLN_modulation.1");   // chunk(6): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        Tn n1 = ln_mod(x, mc, 0, D);
+        Tn qkv = b.conv(bp + ".attn.qkv", n1, 3 * D, 1);
+        b.release(n1);
+        Tn a = b.alloc(B, T, 1, D);
+        {   // timm Attention: qkv.reshape(B, N, 3, heads, hd); q * hd^-0.5; softmax(q k^T) v
+            AttnArgs aa;
+            aa.N = B; aa.Tq = T; aa.Tk = T; aa.heads = c.heads; aa.d = hdim;
+            aa.ldq = aa.ldk = aa.ldv = 3 * D; aa.ldo = D;
+            aa.q_hs = aa.k_hs = aa.v_hs = hdim;
+            aa.scale_q = 1.f / std::sqrt((float)hdim);
+            const size_t qo = qkv.off, ao = a.off;
+            const double fl = 4.0 * B * c.heads * (double)T * T * hdim;
+            b.plan.flops += fl;
+            b.op([=](hipStream_t s) {
+                AttnArgs r = aa;
+                const float* base = reinterpret_cast<const float*>(hd->arena + qo);
+                r.q = base; r.k = base + D; r.v = base + 2 * D;
+                r.out = reinterpret_cast<float*>(hd->arena + ao);
+                attention(r, s);
+            }, 1, "attention", fl);
+        }
+        b.release(qkv);
+        Tn y1 = b.conv(bp + ".attn.proj", a, D, 1);
+        b.release(a);
+        gated(x, y1, mc, 2 * D);
+        b.release(y1);
+        Tn n2 = ln_mod(x, mc, 3 * D, 4 * D);
+        Tn h1 = b.conv(bp + ".mlp.fc1", n2, c.mlp, 1);
+        b.release(n2);
+        {
+            const size_t ho = h1.off;
+            const int64_t cnt = (int64_t)B * T * c.mlp;
+            b.op([=](hipStream_t s) { gelu_tanh(reinterpret_cast<float*>(hd->arena + ho), cnt, s); }, 1, "gelu_tanh", 0.0, 8.0 * cnt);
+        }
+        Tn y2 = b.conv(bp + ".mlp.fc2", h1, D, 1);
+        b.release(h1);
+        gated(x, y2, mc, 5 * D);
+        b.release(y2);
+    }
+    // ---- FinalLayer.forward :138-142 + unpatchify :209-222
+    Tn nf = ln_mod(x, col.at("final_layer.adaLN_modulation.1"), 0, D);
+    b.release(x);
+    const int co = c.cout();
+    Tn o = b.conv("final_layer.linear", nf, p * p * co, 1);
+    b.release(nf);
+    {
+        const size_t oo = o.off;
+        const int hw = c.input / p;
+        b.op([=](hipStream_t s) { unpatchify(reinterpret_cast<const float*>(hd->arena + oo), B, co, hw, hw, p, hd->io.out, s); }, 1, "unpatchify");
+    }
+    b.release(o);
+    b.release(mod);
+}
+
 // --------------------------------------------------------------------------------- single blocks
 void build_block(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
     dsd_handle* hd = b.hd;
@@ -1312,6 +1480,10 @@ void build_block(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
     const int B = b.B;
     const int kind = hd->block_kind;
     const bool token = kind == DSD_BLOCK_CROSSATTN || kind == DSD_BLOCK_FF_GEGLU || kind == DSD_BLOCK_BASIC_TRANSFORMER;
+    if (kind == DSD_BLOCK_DIT) {
+        build_dit(b, C, H, W, aux_len, aux_len2);
+        return;
+    }
     Tn x = b.import_ext(0, B, H, W, C, !token);
     Tn y;
     switch (kind) {

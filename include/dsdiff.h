@@ -239,7 +239,10 @@ enum { DSD_BLOCK_RES = 0, DSD_BLOCK_ATTN = 1, DSD_BLOCK_UPSAMPLE = 2, DSD_BLOCK_
        /* latent path (SURVEY f-3): the KL-VAE of ldm/models/autoencoder.py:26-147 — Encoder / Decoder of
         * ldm/modules/diffusionmodules/model.py:452-655 with quant_conv / post_quant_conv; parameter names are the
         * AutoencoderKL state_dict's ("encoder.down.0.block.0.norm1.weight", "quant_conv.weight", ...) */
-       DSD_BLOCK_VAE_ENCODER = 10, DSD_BLOCK_VAE_DECODER = 11 };
+       DSD_BLOCK_VAE_ENCODER = 10, DSD_BLOCK_VAE_DECODER = 11,
+       /* transformer backbone (SURVEY f-4): DiT of UNet_DS_Diff/DiT_models.py:145-262 (adaLN-Zero blocks, timm-style
+        * PatchEmbed / Attention / Mlp); parameter names are the DiT state_dict's */
+       DSD_BLOCK_DIT = 12 };
 /* iargs by kind:
  *   RES: cin, cout, emb_ch, use_scale_shift_norm, up, down      ATTN: ch, heads, new_order
  *   UPSAMPLE/DOWNSAMPLE: ch     DISENTANGLE: ch, half_ch       SE: ch, reduction
@@ -249,7 +252,11 @@ enum { DSD_BLOCK_RES = 0, DSD_BLOCK_ATTN = 1, DSD_BLOCK_UPSAMPLE = 2, DSD_BLOCK_
  *   VAE_ENCODER / VAE_DECODER: ch, out_ch, in_channels, resolution, z_channels, double_z, embed_dim, num_res_blocks,
  *        with_quant (1: AutoencoderKL.encode / decode incl. quant_conv / post_quant_conv, 0: bare Encoder / Decoder),
  *        len(ch_mult), ch_mult..., len(attn_resolutions), attn_resolutions...    (configs/autoencoder_kl_64x64x3.yaml:14-24)
- *        encoder: x [B,in_channels,H,W] -> moments [B,2*embed_dim,H/f,W/f];  decoder: z [B,embed_dim,h,w] -> [B,out_ch,h*f,w*f] */
+ *        encoder: x [B,in_channels,H,W] -> moments [B,2*embed_dim,H/f,W/f];  decoder: z [B,embed_dim,h,w] -> [B,out_ch,h*f,w*f]
+ *   DIT: input_size, patch_size, in_channels, hidden_size, depth, num_heads, mlp_hidden, num_classes, learn_sigma,
+ *        use_cfg_embedding.  x [B,in_channels,S,S] (x and cond already concatenated), aux = timesteps [B] fp32 (aux_len 1),
+ *        aux2 = class labels [B] int64 or NULL (aux_len2 1 / 0); out [B, out_channels, S, S].  dsd_set_timestep_freqs
+ *        (128 entries) installs the caller's frequency table as for the U-Net. */
 int dsd_block_create(int kind, const int32_t* iargs, int n_iargs, int device, dsd_handle** out);
 /* x: NCHW [B,C,H,W] (token blocks: [B,N,C] passed as H=N, W=1 "NHWC"), aux: emb [B,emb_ch] for RES,
  * context [B,Nc,Cc] for cross-attention kinds (aux2/aux_len2 = second context for depth-2 spatial

@@ -1,0 +1,94 @@
+"""Transformer backbone (BASELINE config 5): DiT of UNet_DS_Diff/DiT_models.py behind the C ABI
+(DSD_BLOCK_DIT) against oracle/dit.py.
+
+PARITY UNPINNED BY THE REFERENCE: DiT_models.py needs timm, absent from the image, so no reference-generated fixture exists
+and the reference holds no test or golden vector for this path; the oracle restates DiT.forward with timm's PatchEmbed /
+Attention / Mlp written out from their published definition.  Tolerance 1e-5 rel-L2 (fp32 re-association over the depth)."""
+import pytest
+import torch
+
+from oracle import dit as OD
+from oracle.synth import synth_params
+from util import rel_l2, randn
+
+pytestmark = pytest.mark.gpu
+
+
+def make(**kw):
+    from diffusion_models_dsdiff_amd.UNet_DS_Diff.DiT_models import DiT
+    m = DiT(**kw)
+    sd = synth_params([(k, tuple(v.shape)) for k, v in m.state_dict().items()], 901)
+    m.load_state_dict(sd, strict=True)
+    return m, sd
+
+
+def test_dit_state_dict_names_and_default_init():
+    from diffusion_models_dsdiff_amd.UNet_DS_Diff.DiT_models import DiT, get_2d_sincos_pos_embed
+    m = DiT(input_size=16, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=4, num_classes=10)
+    names = set(m.state_dict().keys())
+    want = {"x_embedder.proj.weight", "x_embedder.proj.bias", "t_embedder.mlp.0.weight", "t_embedder.mlp.2.bias",
+            "y_embedder.embedding_table.weight", "pos_embed", "blocks.0.attn.qkv.weight", "blocks.1.attn.proj.bias",
+            "blocks.0.mlp.fc1.weight", "blocks.1.mlp.fc2.bias", "blocks.1.adaLN_modulation.1.weight", "final_layer.linear.weight",
+            "final_layer.adaLN_modulation.1.bias"}
+    assert want <= names and len(names) == 2 + 4 + 1 + 1 + 2 * 10 + 4
+    assert m.state_dict()["y_embedder.embedding_table.weight"].shape == (11, 64)      # + the classifier-free-guidance row
+    assert m.state_dict()["x_embedder.proj.weight"].shape == (64, 4, 2, 2) and m.out_channels == 2   # in_channels // 3 * 2 (sic)
+    assert torch.allclose(m.state_dict()["pos_embed"][0], torch.from_numpy(get_2d_sincos_pos_embed(64, 8)).float())
+    y = m(randn((2, 4, 16, 16), 1).cuda(), torch.tensor([3, 900]).cuda())            # zero output layer at default init
+    assert y.shape == (2, 2, 16, 16) and float(y.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("kw,labels", [
+    (dict(input_size=16, patch_size=2, in_channels=4, hidden_size=64, depth=2, num_heads=4, num_classes=10), True),
+    (dict(input_size=32, patch_size=4, in_channels=3, hidden_size=96, depth=3, num_heads=3, num_classes=5, learn_sigma=False,
+          class_dropout_prob=0.0), False),
+    (dict(input_size=64, patch_size=8, in_channels=4, hidden_size=768, depth=2, num_heads=12, num_classes=1000), True),   # DiT-B/8 blocks
+])
+def test_dit_forward_vs_oracle(kw, labels):
+    m, sd = make(**kw)
+    N = 2
+    x = randn((N, kw["in_channels"] - 1, kw["input_size"], kw["input_size"]), 5)
+    cond = randn((N, 1, kw["input_size"], kw["input_size"]), 6)                     # forward(x, t, y, cond): cat along channels
+    t = torch.tensor([17.0, 999.0])
+    y = torch.tensor([1, 4]) if labels else None
+    want = OD.dit_forward(sd, torch.cat([x, cond], 1), t, y, patch_size=kw["patch_size"], num_heads=kw["num_heads"],
+                          out_channels=m.out_channels)
+    assert float(want.abs().max()) > 1e-3
+    for prec, tol in (("bf16x6", 1e-5), ("f32", 1e-5), ("f16x3", 2e-5)):
+        m.set_precision(prec)
+        got = m(x.cuda(), t.cuda(), None if y is None else y.cuda(), cond=cond.cuda())
+        err = rel_l2(got, want)
+        print(f"DiT {kw['hidden_size']}x{kw['depth']} p{kw['patch_size']} {prec}: rel-L2 vs oracle {err:.3e}")
+        assert got.shape == want.shape and err < tol, prec
+    m.set_precision("bf16x6")
+    assert torch.equal(m(x.cuda(), t.cuda(), None if y is None else y.cuda(), cond=cond.cuda()),
+                       m(x.cuda(), t.cuda(), None if y is None else y.cuda(), cond=cond.cuda()))
+
+
+def test_dit_b8_at_512_properties():
+    """BASELINE config 5 shape: DiT-B/8 on 512x512 (4096 tokens, 12 heads of 64), two blocks of it: finite, deterministic,
+    batch rows independent, and equal to the oracle on one slice."""
+    from diffusion_models_dsdiff_amd.UNet_DS_Diff.DiT_models import DiT
+    kw = dict(input_size=512, patch_size=8, in_channels=4, hidden_size=768, depth=2, num_heads=12, num_classes=1000)
+    m, sd = make(**kw)
+    x = randn((2, 4, 512, 512), 11)
+    t = torch.tensor([500.0, 3.0])
+    got = m(x.cuda(), t.cuda())
+    assert bool(torch.isfinite(got).all()) and torch.equal(got, m(x.cuda(), t.cuda()))
+    alone = m(x[1:].cuda(), t[1:].cuda())
+    assert rel_l2(alone, got[1:]) < 1e-6
+    want = OD.dit_forward(sd, x[:1], t[:1], None, patch_size=8, num_heads=12, out_channels=m.out_channels)
+    assert rel_l2(got[:1], want) < 1e-5
+
+
+def test_dit_rejects_bad_input():
+    from diffusion_models_dsdiff_amd import _lib
+    m, _ = make(input_size=16, patch_size=2, in_channels=4, hidden_size=64, depth=1, num_heads=4, num_classes=0)
+    with pytest.raises(_lib.DsdError):
+        m(torch.zeros(1, 4, 32, 32).cuda(), torch.tensor([1.0]).cuda())       # pos_embed is for 16x16
+    with pytest.raises(_lib.DsdError):
+        m(torch.zeros(1, 3, 16, 16).cuda(), torch.tensor([1.0]).cuda())       # channel count
+    with pytest.raises(_lib.DsdError):
+        m(torch.zeros(1, 4, 16, 16).cuda(), torch.tensor([1.0]).cuda(), torch.tensor([0]).cuda())   # labels without a table
+    with pytest.raises(_lib.DsdError):
+        m(torch.zeros(1, 4, 16, 16), torch.tensor([1.0]))                       # CPU tensors

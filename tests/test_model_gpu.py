@@ -373,7 +373,7 @@ def test_gn_statistics_from_conv_epilogue_match_the_standalone_pass(B, full_mode
     m.fuse_gn_stats(True)
     y1 = m._run(x2, t2, want_feats=False)[0]
     n1 = m.plan_info()["launches"]
-    assert rel_l2(y1, y0) < 2e-6 and n1 < n0 - 100, (n0, n1)        # most of the 191 statistics launches are gone
+    assert rel_l2(y1, y0) < 5e-6 and n1 < n0 - 50, (n0, n1)         # most statistics launches are gone (191 at batch 16)
     assert torch.equal(y1, m._run(x2, t2, want_feats=False)[0])     # deterministic
 
 

@@ -14,6 +14,8 @@ if os.environ.get("DSD_SHAPES") == "wino":   # 3x3 stride-1 layers the F(2,3) ke
     SHAPES = [(16, 256, 256, 320, 320, 3, 1), (16, 256, 256, 640, 320, 3, 1), (16, 128, 128, 320, 320, 3, 1), (16, 64, 64, 640, 640, 3, 1),
               (16, 32, 32, 640, 640, 3, 1), (16, 16, 16, 960, 960, 3, 1), (16, 64, 64, 1280, 640, 3, 1), (1, 256, 256, 320, 320, 3, 1),
               (1, 128, 128, 320, 320, 3, 1), (1, 64, 64, 640, 640, 3, 1)]
+if os.environ.get("DSD_SHAPES") == "wino2":
+    SHAPES = [(16, 256, 256, 320, 320, 3, 1), (16, 64, 64, 640, 640, 3, 1), (16, 128, 128, 256, 256, 3, 1)]
 if os.environ.get("DSD_SHAPES") == "small":
     SHAPES = [(16, 16, 16, 960, 960, 3, 1), (16, 8, 8, 960, 960, 3, 1), (16, 8, 8, 1920, 960, 3, 1), (16, 16, 16, 960, 2880, 1, 1),
               (16, 8, 8, 960, 480, 1, 1), (16, 8, 8, 2880, 960, 1, 1), (16, 16, 16, 1920, 960, 1, 1), (16, 32, 32, 640, 1920, 1, 1)]
