@@ -53,7 +53,8 @@ struct WinoP {
     const float* res;
     float* y;
     int64_t x_bs;
-    int N, H, W, Cin, Cout, emb_stride, y_ld;
+    int N, H, W, Cin, Cout, emb_stride, y_ld;   // H, W: OUTPUT size (= input size, or twice it with the folded nearest x2)
+    int ups, IW;                                  // ups: the input is [N, H >> 1, W >> 1, Cin], pixel (h, w) reads (h >> 1, w >> 1)
     int M, T, halfW, ohw, tps;   // output pixels, tiles (= M/2), tiles per image row, pixels / tiles per sample
     int KT, cchunks;             // k-tiles = 3 * Cin/16
     int tiles_m, tiles_n;
@@ -94,6 +95,22 @@ __device__ __forceinline__ void split8x3(f32x4 lo, f32x4 hi, bf16x8 (&out)[3]) {
 // NT = column tiles (of 32 output channels) this block really has: 4, or 2 in the last N tile of a layer whose Cout is
 // 64 (mod 128).  A compile-time count: a run-time `if (j < ntv)` around the MFMAs makes every accumulator a phi of
 // "multiplied / not multiplied", which doubles the AGPR demand and spills the whole accumulator file.
+//
+// Version 2 of the activation path.  Version 1 had every lane fetch its four pixels x 32 B straight from global memory
+// (8 buffer loads per k-tile, each touching 64 different 128-byte lines): measured, the kernel ran no faster than the direct
+// one although it issues 1.5x fewer MFMAs, and removing those loads alone (what-if build) recovered the difference — the
+// texture-address path, not the matrix pipe, was the limit.  Now the block's pixels come in by LDS-DMA as 64-byte entries
+// (16 channels of one pixel = half a cache line, 16 entries per wave-instruction), even and odd image columns in two
+// arrays so that the tiles' neighbours are neighbouring entries, XOR-swizzled through the SOURCE address so that the
+// fragment reads are bank-conflict-free; lanes then read their four pixels from LDS.  Three activation stages: the tile
+// after next is in flight while the next one is already readable, because the first product of a tile needs its
+// activations transformed BEFORE its barrier.
+static constexpr int AENT = 64;                       // bytes of one pixel entry: 16 channels fp32
+static constexpr int ASTAGE = 2 * WTILES * AENT;      // even-column entries [128] | odd-column entries [128] = 16 KB
+static constexpr int A_BASE = 2 * WSTAGE;             // activation stages follow the two weight stages
+static constexpr int Z_OFF = A_BASE + 3 * ASTAGE;     // 64 zero bytes: every padding pixel reads here
+static constexpr int WLDS = Z_OFF + 64;
+
 template <int NT>
 __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
@@ -112,34 +129,71 @@ __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
     const int tile_m = L / p.tiles_n;
     const int t0 = tile_m * WTILES;
     const int n0 = tile_n * WBROWS;
+    if (tid < 4) *reinterpret_cast<f32x4*>(Bs + Z_OFF + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // ---- this lane's tile: output pixels (n, oh, 2 tw) and (n, oh, 2 tw + 1); input pixels (oh - 1 + kh, 2 tw - 1 + j)
-    const int t = t0 + wave * 32 + lrow;
+    // ---- compute role: this lane's tile = output pixels (n, oh, 2 tw), (n, oh, 2 tw + 1); its input pixels of filter row
+    // kh are columns 2 tw - 1 .. 2 tw + 2 of image row oh - 1 + kh = entries O[tl-1], E[tl], O[tl], E[tl+1] (tl = tile index
+    // inside the block; a block starts at an image-row start, so the entries outside 0..127 are exactly the zero padding)
+    const int tl = wave * 32 + lrow;
+    const int t = t0 + tl;
     const bool a_ok = t < p.T;
-    const int tt = a_ok ? t : 0;
+    const int tt = a_ok ? t : p.T - 1;
     const int ns = tt / p.tps;
     const int rem = tt - ns * p.tps;
     const int oh = rem / p.halfW;
     const int tw = rem - oh * p.halfW;
-    unsigned rowoff[3], coloff[4];
-    bool rowok[3], colok[4];
+    // stage-relative byte offsets of the two 16-byte slots (this lane's 8 channels) of its four pixels; slot s of entry i
+    // lives at physical slot s ^ ((i >> 2) & 3)
+    int aoff[4][2];
+    {
+        const int idx[4] = {tl - 1, tl, tl, tl + 1};
+        const int arr[4] = {1, 0, 1, 0};   // O, E, O, E
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int ih = oh - 1 + kh;
-        rowok[kh] = a_ok & ((unsigned)ih < (unsigned)p.H);
-        rowoff[kh] = ((unsigned)ns * (unsigned)p.x_bs + (unsigned)(ih * p.W) * (unsigned)p.Cin + (unsigned)(half * 8)) * 4u;
-    }
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int iw = 2 * tw - 1 + j;
-        colok[j] = (unsigned)iw < (unsigned)p.W;
-        coloff[j] = (unsigned)iw * (unsigned)p.Cin * 4u;
+            for (int sl = 0; sl < 2; ++sl)
+                aoff[j][sl] = arr[j] * (WTILES * AENT) + idx[j] * AENT + (((half * 2 + sl) ^ ((idx[j] >> 2) & 3)) << 4);
     }
+    const bool padl = tw == 0, padr = tw == p.halfW - 1;
+    const unsigned okmask = ((unsigned)(oh - 1) < (unsigned)p.H ? 1u : 0u) | 2u | ((unsigned)(oh + 1) < (unsigned)p.H ? 4u : 0u);
+
+    // ---- loader role: LDS-DMA chunk q = (wave*4 + i)*64 + lane of an activation stage: entry e = q >> 2 (array e >> 7,
+    // index e & 127), physical slot q & 3 holding logical slot (q & 3) ^ ((index >> 2) & 3) of that pixel's 64 bytes
+    unsigned dcol[4];
+    int doh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = (wave * 4 + i) * 64 + lane;
+        const int e = q >> 2, arr = e >> 7, idx = e & 127;
+        const int ls = (q & 3) ^ ((idx >> 2) & 3);
+        const int tg = min(t0 + idx, p.T - 1);
+        const int gn = tg / p.tps;
+        const int gr = tg - gn * p.tps;
+        const int goh = gr / p.halfW;
+        const int gtw = gr - goh * p.halfW;
+        doh[i] = goh;
+        // byte offset of (row 0, source column of output column 2 gtw + arr, channel 4 ls) of sample gn
+        dcol[i] = ((unsigned)gn * (unsigned)p.x_bs + (unsigned)((2 * gtw + arr) >> p.ups) * (unsigned)p.Cin + (unsigned)(ls * 4)) * 4u;
+    }
+    const unsigned rowpitch = (unsigned)p.IW * (unsigned)p.Cin * 4u;
+    auto dma_a = [&](int kt, int stage_off) {
+        if (kt >= p.KT) return;
+        const int cc = kt / 3, kh = kt - cc * 3;
+        const int soff = __builtin_amdgcn_readfirstlane(cc * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ih = doh[i] - 1 + kh;
+            const unsigned v = (unsigned)ih < (unsigned)p.H ? dcol[i] + (unsigned)(ih >> p.ups) * rowpitch : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (void __attribute__((address_space(3)))*)(Bs + stage_off + (wave * 4 + i) * 1024),
+                                                     16, v, soff, 0, 0);
+        }
+    };
 
     // ---- weights: the k-tile kt of this N tile is WSTAGE contiguous bytes; LDS-DMA chunk q = i*256 + tid lands at LDS byte
     // q*16 (lane-linear) and must hold the logical chunk q ^ ((q >> 4) & 1)  ((q>>4)&1 = (row>>3)&1 of the chunk's row)
     const unsigned char* wt = p.wp + (size_t)tile_n * p.KT * WSTAGE + (size_t)((tid ^ ((tid >> 4) & 1)) * 16);
-    auto dma_tile = [&](int kt, int so) {
+    auto dma_b = [&](int kt, int so) {
+        if (kt >= p.KT) return;
         const unsigned char* src = wt + (size_t)kt * WSTAGE;
 #pragma unroll
         for (int i = 0; i < WSTAGE / 4096; ++i)
@@ -157,34 +211,14 @@ __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[q][j][e] = 0.f;
 
-    // activations: raw[set][pixel j][16-byte half]; after the in-place transform raw[set][q] holds U_q
-    f32x4 raw[2][4][2];
     bf16x8 af[4][3];
-    auto load_raw = [&](int set, int kt) {
-        // clamped: the look-ahead past the last k-tile re-reads the last one (its data is never multiplied)
-        const int k = min(kt, p.KT - 1);
-        const int cc = k / 3, kh = k - cc * 3;
-        const int soff = __builtin_amdgcn_readfirstlane(cc * 64);
-        const unsigned ro = kh == 0 ? rowoff[0] : (kh == 1 ? rowoff[1] : rowoff[2]);
-        const bool rk = kh == 0 ? rowok[0] : (kh == 1 ? rowok[1] : rowok[2]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const bool ok = rk & colok[j];
-            const unsigned v0 = ok ? ro + coloff[j] : OOB;
-            const unsigned v1 = ok ? ro + coloff[j] + 16u : OOB;
-            raw[set][j][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, v0, soff, 0));
-            raw[set][j][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, v1, soff, 0));
-        }
-    };
-    auto transform = [&](int set) {   // d0..d3 -> U0 = d0-d2, U1 = d1+d2, U2 = d2-d1, U3 = d1-d3 (in place)
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f32x4 d0 = raw[set][0][h], d1 = raw[set][1][h], d2 = raw[set][2][h], d3 = raw[set][3][h];
-            raw[set][0][h] = d0 - d2;
-            raw[set][1][h] = d1 + d2;
-            raw[set][2][h] = d2 - d1;
-            raw[set][3][h] = d1 - d3;
-        }
+    // pixel j of filter row kh from the activation stage at byte offset `st` (zero entry for padding)
+    auto rd = [&](int j, int st, int kh, f32x4& lo, f32x4& hi) {
+        const bool pad = (j == 0 && padl) || (j == 3 && padr) || !((okmask >> kh) & 1u);
+        const int a0 = pad ? Z_OFF : st + aoff[j][0];
+        const int a1 = pad ? Z_OFF + 16 : st + aoff[j][1];
+        lo = *reinterpret_cast<const f32x4*>(Bs + a0);
+        hi = *reinterpret_cast<const f32x4*>(Bs + a1);
     };
     auto mfma6 = [&](const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16& c) {   // smallest terms first
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
@@ -195,61 +229,70 @@ __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
     };
 
-    // ---- prologue: weights of tile 0 -> stage 0; activations of tile 0 -> af[0..2] and U_3 (left in raw[0][3], split at
-    // position 0 of tile 0 like in every other tile), of tile 1 -> raw[1] (in flight)
-    dma_tile(0, 0);
-    load_raw(0, 0);
-    transform(0);
-#pragma unroll
-    for (int q = 0; q < 3; ++q) split8x3(raw[0][q][0], raw[0][q][1], af[q]);
-    load_raw(1, 1);
+    // ---- prologue: weights of tile 0, activations of tiles 0 and 1; after the barrier U_0 of tile 0 is formed (the only
+    // transform that is not hidden behind MFMAs)
+    dma_b(0, 0);
+    dma_a(0, A_BASE);
+    dma_a(1, A_BASE + ASTAGE);
+    __syncthreads();
+    f32x4 d1l, d1h, d2l, d2h, xl, xh, yl, yh;
+    rd(0, A_BASE, 0, xl, xh);
+    rd(2, A_BASE, 0, yl, yh);
+    split8x3(xl - yl, xh - yh, af[0]);
 
-    // One k-tile = 4 positions x NT units of 6 MFMAs.  While tile kt is multiplied (position-major):
-    //   start         the LDS-DMA of the weights of tile kt+1 into the other stage (a whole tile to land)
-    //   position 0    af[3] of THIS tile from the U_3 kept since the previous tile
-    //   after pos. 1  the activations of tile kt+1 (loaded during tile kt-1) are transformed in place; U_0, U_1 -> af[0], af[1]
-    //                 (dead for this tile), then the loads of tile kt+2 go out into the other register set
-    //   after pos. 2  U_2 -> af[2];   U_3 stays in its registers until position 0 of the next tile
-    // so the activation fragments need no second buffer.  `cur` = register set holding tile kt+1.
-    // The two register sets alternate by tile parity, so the loop body is TWO k-tiles of straight-line code (KT = 3 * Cin/16
-    // is even: Cin % 32 == 0).  No branch may surround an MFMA: the 256 accumulators fill the AGPR file, and a control-flow
-    // join would need copies of them.
-#define DSD_WINO_TILE(KT_, SO, CUR, OTH)                                                                                     \
-    {                                                                                                                        \
-        __syncthreads(); /* DMA of this tile has landed (vmcnt(0) before the barrier); every wave left the other stage */    \
-        if ((KT_) + 1 < p.KT && !(p.whatif & 2)) dma_tile((KT_) + 1, WSTAGE - (SO));                                         \
-        const unsigned char* bf = Bs + (SO) + frag_off;                                                                      \
-        bf16x8 b_cur[3], b_nxt[3];                                                                                           \
-        _Pragma("unroll") for (int q = 0; q < 3; ++q) b_nxt[q] = b_cur[q] = *reinterpret_cast<const bf16x8*>(bf + (q * 4) * WPLANE); \
-        __builtin_amdgcn_sched_barrier(0);                                                                                   \
-        _Pragma("unroll") for (int u = 0; u < 4 * NT; ++u) {                                                                 \
-            const int pos = u / NT, j = u % NT;                                                                              \
-            if (u + 1 < 4 * NT) {                                                                                            \
-                const int pos1 = (u + 1) / NT, j1 = (u + 1) % NT;                                                            \
-                _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                                \
-                    b_nxt[q] = *reinterpret_cast<const bf16x8*>(bf + (q * 4 + pos1) * WPLANE + j1 * 32 * 32);                \
-            }                                                                                                                \
-            __builtin_amdgcn_sched_barrier(0);                                                                               \
-            if (!(p.whatif & 4)) {                                                                                           \
-                if (u == 0) split8x3(raw[OTH][3][0], raw[OTH][3][1], af[3]);                                                 \
-                if (u == 2 * NT) {                                                                                           \
-                    transform(CUR);                                                                                          \
-                    split8x3(raw[CUR][0][0], raw[CUR][0][1], af[0]);                                                         \
-                }                                                                                                            \
-                if (u == 2 * NT + 1) split8x3(raw[CUR][1][0], raw[CUR][1][1], af[1]);                                        \
-                if (u == 3 * NT) split8x3(raw[CUR][2][0], raw[CUR][2][1], af[2]);                                            \
-            }                                                                                                                \
-            if (u == 2 * NT + 2 && !(p.whatif & 1)) load_raw(OTH, (KT_) + 2);                                                \
-            mfma6(af[pos], b_cur, acc[pos][j]);                                                                              \
-            _Pragma("unroll") for (int q = 0; q < 3; ++q) b_cur[q] = b_nxt[q];                                               \
-            __builtin_amdgcn_sched_barrier(0);                                                                               \
-        }                                                                                                                    \
+    // One k-tile = 4 positions x NT units of 6 MFMAs, position-major; the transform of each position runs one position ahead
+    // of its products, spread over the units of the position before:
+    //   during position 0:  d1, d2 of this tile -> U_1 = d1 + d2 -> af[1]
+    //   during position 1:  U_2 = d2 - d1 -> af[2];  d3 is read
+    //   during position 2:  U_3 = d1 - d3 -> af[3];  d0, d2 of the NEXT tile are read (its stage is already visible)
+    //   during position 3:  U_0 = d0 - d2 of the next tile -> af[0]
+    // and at the top of the tile the DMAs of the weights of tile kt+1 and of the activations of tile kt+2 go out.
+    int kh = 0, ast = 0;   // filter row of tile kt; index (0..2) of its activation stage
+    for (int kt = 0; kt < p.KT; ++kt) {
+        const int so = (kt & 1) * WSTAGE;
+        const int st_cur = A_BASE + ast * ASTAGE;
+        const int ast1 = ast == 2 ? 0 : ast + 1, ast2 = ast1 == 2 ? 0 : ast1 + 1;
+        const int st_nxt = A_BASE + ast1 * ASTAGE;
+        const int kh1 = kh == 2 ? 0 : kh + 1;
+        dma_b(kt + 1, WSTAGE - so);
+        dma_a(kt + 2, A_BASE + ast2 * ASTAGE);
+        const unsigned char* bf = Bs + so + frag_off;
+        bf16x8 b_cur[3], b_nxt[3];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) b_nxt[q] = b_cur[q] = *reinterpret_cast<const bf16x8*>(bf + (q * 4) * WPLANE);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4 * NT; ++u) {
+            const int pos = u / NT, j = u % NT;
+            if (u + 1 < 4 * NT) {
+                const int pos1 = (u + 1) / NT, j1 = (u + 1) % NT;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    b_nxt[q] = *reinterpret_cast<const bf16x8*>(bf + (q * 4 + pos1) * WPLANE + j1 * 32 * 32);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (u == 0) {
+                rd(1, st_cur, kh, d1l, d1h);
+                rd(2, st_cur, kh, d2l, d2h);
+            }
+            if (u == NT - 1) split8x3(d1l + d2l, d1h + d2h, af[1]);
+            if (u == NT) rd(3, st_cur, kh, xl, xh);
+            if (u == 2 * NT - 1) split8x3(d2l - d1l, d2h - d1h, af[2]);
+            if (u == 2 * NT) {
+                rd(0, st_nxt, kh1, yl, yh);
+                rd(2, st_nxt, kh1, d2l, d2h);
+            }
+            if (u == 3 * NT - 1) split8x3(d1l - xl, d1h - xh, af[3]);
+            if (u == 4 * NT - 1) split8x3(yl - d2l, yh - d2h, af[0]);
+            mfma6(af[pos], b_cur, acc[pos][j]);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) b_cur[q] = b_nxt[q];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();   // DMAs issued at the top have landed (vmcnt(0) before the barrier); every wave left this tile's stages
+        kh = kh1;
+        ast = ast1;
     }
-    for (int kt = 0; kt < p.KT; kt += 2) {
-        DSD_WINO_TILE(kt, 0, 1, 0)
-        DSD_WINO_TILE(kt + 1, WSTAGE, 0, 1)
-    }
-#undef DSD_WINO_TILE
 
     // ---- epilogue: y0 = Y0 + Y1 + Y2, y1 = Y1 - Y2 - Y3, + bias + per-(sample, channel) embedding + residual
     // GroupNorm statistics as shifted fp32 partials per lane and column (see StatAcc in conv_split.hip for why shifted)
@@ -330,7 +373,7 @@ __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
 }
 
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoP p) {
-    __shared__ __attribute__((aligned(1024))) unsigned char Bs[2 * WSTAGE];
+    __shared__ __attribute__((aligned(1024))) unsigned char Bs[WLDS];
     int L = blockIdx.x;
     {
         const int cpx = (int)gridDim.x >> 3;
@@ -383,37 +426,41 @@ void wino_pack_weights(const float* w_ohwi, int Cout, int Cin, void* packed, hip
     check_launch("wino_pack");
 }
 
-// 3x3, stride 1, symmetric padding, no folded upsample, even output width, Cin % 16 == 0, Cout % 32 == 0, bf16x6 arithmetic,
+// 3x3, stride 1, symmetric padding, no folded upsample, width a power of two <= 256, Cin % 32 == 0, Cout = 0 or 64 (mod 128), bf16x6,
 // operands addressable with 32-bit byte offsets, and enough tiles to fill the chip (small grids keep the split-K kernels)
 bool conv2d_wino_eligible(const ConvArgs& a) { return a.w_wino != nullptr && conv2d_wino_shape_ok(a); }
 
 bool conv2d_wino_shape_ok(const ConvArgs& a) {
     static const bool off = getenv("DSD_NO_WINOGRAD") != nullptr;   // experiments only
-    if (off || a.ks != 3 || a.stride != 1 || a.ups || a.pad_lo >= 0 || a.pad_total >= 0 || a.out_nchw) return false;
+    if (off || a.ks != 3 || a.stride != 1 || a.pad_lo >= 0 || a.pad_total >= 0 || a.out_nchw) return false;
     if (a.precision != PREC_BF16X6) return false;
-    if (a.W % 2 != 0 || a.Cin % 32 != 0 || (a.Cout % WBROWS != 0 && a.Cout % WBROWS != 64)) return false;
+    const int OW = a.ups ? 2 * a.W : a.W, OH = a.ups ? 2 * a.H : a.H;
+    if (OW % 2 != 0 || a.Cin % 32 != 0 || (a.Cout % WBROWS != 0 && a.Cout % WBROWS != 64)) return false;
+    if (WTILES % (OW / 2) != 0) return false;   // a block (128 tiles) must start at an image-row start: output W = 2, 4, ..., 256
     const int64_t x_bs = a.x_bs >= 0 ? a.x_bs : (int64_t)a.H * a.W * a.Cin;
     const int64_t xb = ((int64_t)(a.N - 1) * x_bs + (int64_t)a.H * a.W * a.Cin) * 4;
     if (xb >= 0xFFFFFF00ll) return false;
-    const int64_t M = (int64_t)a.N * a.H * a.W;
+    const int64_t M = (int64_t)a.N * OH * OW;
     return M >= 4096 && M < (1ll << 31);
 }
 
 int conv2d_wino_stats_chunks(const ConvArgs& a) {
-    const int ohw = a.H * a.W;
+    const int ohw = (a.ups ? 4 : 1) * a.H * a.W;
     return ohw % (2 * WTILES) == 0 ? ohw / (2 * WTILES) : 0;
 }
 
 void conv2d_wino(const ConvArgs& a, hipStream_t s) {
     WinoP p{};
     p.x = a.x; p.wp = (const unsigned char*)a.w_wino; p.bias = a.bias; p.emb = a.emb; p.res = a.res; p.y = a.y;
-    p.N = a.N; p.H = a.H; p.W = a.W; p.Cin = a.Cin; p.Cout = a.Cout; p.emb_stride = a.emb_stride;
+    p.N = a.N; p.Cin = a.Cin; p.Cout = a.Cout; p.emb_stride = a.emb_stride;
+    p.ups = a.ups ? 1 : 0;
+    p.H = a.H << p.ups; p.W = a.W << p.ups; p.IW = a.W;
     p.y_ld = a.y_ld > 0 ? a.y_ld : a.Cout;
     p.x_bs = a.x_bs >= 0 ? a.x_bs : (int64_t)a.H * a.W * a.Cin;
-    p.ohw = a.H * a.W;
+    p.ohw = p.H * p.W;
     p.M = (int)((int64_t)a.N * p.ohw);
     p.T = p.M / 2;
-    p.halfW = a.W / 2;
+    p.halfW = p.W / 2;
     p.tps = p.ohw / 2;
     p.cchunks = a.Cin / 16;
     p.KT = 3 * p.cchunks;

@@ -1,0 +1,189 @@
+"""Host side of the inference entry points, either side of the sampling path — numpy only.
+
+What the reference does around ``sample_fn`` and what is rebuilt here:
+  * slice bookkeeping of ``predict_step`` / ``on_predict_batch_end`` / ``on_predict_end``
+    (trainers/trainer_use_gaussian_diff.py:602-655): ``.../<id>/<name>_<slice>.h5`` paths -> (id, slice index), 2-D samples
+    collected per id and written back into a zero-filled [D,H,W] volume shaped like the template  -> ``parse_slice_path``,
+    ``VolumeAssembler``;
+  * the volume file format: the reference reads / writes NIfTI through SimpleITK (``sitk.ReadImage`` /
+    ``CopyInformation`` / ``WriteImage``, :639-648).  SimpleITK is not installable here, so ``read_nifti`` /
+    ``write_nifti`` implement the single-file NIfTI-1 container (348-byte header + voxel block, optionally gzipped) from its
+    public specification; "CopyInformation" = the prediction is written with the template's header (geometry) bytes;
+  * the array-level metrics of inference/test_metrics.py:21-26,149-224 (scale12bit, NRMSE, MAPE, sMAPE, logac, medsymac) and
+    PSNR (:378-400, skimage's definition) as used by inference/get_metric_BraTs.py.
+Not rebuilt: the h5 slice reader (training_project/utils/my_transform.py:142-154: one ``h5py.File(path)[key][()]`` per key —
+the HDF5 container needs h5py, absent from the image; ``infer_2d.py`` takes ``.npy`` slices instead), SSIM / FID / LPIPS / ANTs
+similarity (skimage, torchmetrics, lpips, ants).
+
+PARITY UNPINNED: inference/test_metrics.py and the trainers do not import here (ants, lpips, SimpleITK, Lightning), and
+the reference holds no fixtures for these functions; tests/test_host_io.py checks them against their defining formulas.
+"""
+from __future__ import annotations
+
+import gzip
+import os
+import struct
+from collections import defaultdict
+from typing import Dict, Iterable, Optional, Tuple
+
+import numpy as np
+
+
+# ------------------------------------------------------------------------------------------------ slice bookkeeping
+def parse_slice_path(path: str) -> Tuple[str, int]:
+    """trainer_use_gaussian_diff.py:608-609: id = parent directory name, slice index = the integer after the last '_'."""
+    return path.split("/")[-2], int(os.path.basename(path).split(".")[0].split("_")[-1])
+
+
+class VolumeAssembler:
+    """on_predict_batch_end / on_predict_end (:625-655): collect 2-D samples per volume id, then stack them into
+    ``np.zeros_like(template)`` at their slice index (slices that were never predicted stay zero)."""
+
+    def __init__(self):
+        self.pred: Dict[str, Dict[int, np.ndarray]] = defaultdict(dict)
+
+    def add_batch(self, ids: Iterable[str], slice_idx: Iterable[int], images) -> None:
+        images = np.asarray(images.detach().cpu().numpy() if hasattr(images, "detach") else images)
+        for id_, si, img in zip(ids, slice_idx, images):
+            self.pred[id_][int(si)] = np.asarray(img)
+
+    def add_paths(self, paths: Iterable[str], images) -> None:
+        parsed = [parse_slice_path(p) for p in paths]
+        self.add_batch([p[0] for p in parsed], [p[1] for p in parsed], images)
+
+    def ids(self):
+        return list(self.pred.keys())
+
+    def volume(self, id_: str, template: Optional[np.ndarray] = None, depth: Optional[int] = None) -> np.ndarray:
+        slices = self.pred[id_]
+        if template is not None:
+            vol = np.zeros_like(template)
+        else:
+            first = next(iter(slices.values()))
+            hw = first.shape[-2:]
+            vol = np.zeros((depth if depth is not None else max(slices) + 1,) + tuple(hw), dtype=first.dtype)
+        for si, img in slices.items():
+            vol[si] = img.reshape(vol.shape[1:])      # a [1,H,W] sample broadcasts into pred_array[slice] the same way (:646)
+        return vol
+
+
+# ------------------------------------------------------------------------------------------------ NIfTI-1 container
+_NIFTI_DTYPES = {2: np.uint8, 4: np.int16, 8: np.int32, 16: np.float32, 64: np.float64, 256: np.int8, 512: np.uint16,
+                 768: np.uint32}
+_NIFTI_CODES = {np.dtype(v).str[1:]: k for k, v in _NIFTI_DTYPES.items()}
+
+
+def read_nifti(path: str):
+    """-> (array [D,H,W] in SimpleITK's GetArrayFromImage order (z, y, x), header bytes).  Single-file NIfTI-1
+    (.nii / .nii.gz), 3-D, scl_slope / scl_inter applied when set."""
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rb") as f:
+        raw = f.read()
+    hdr = raw[:348]
+    end = "<" if struct.unpack("<i", hdr[:4])[0] == 348 else ">"
+    if struct.unpack(end + "i", hdr[:4])[0] != 348:
+        raise ValueError(f"{path}: not a NIfTI-1 file")
+    dim = struct.unpack(end + "8h", hdr[40:56])
+    datatype, bitpix = struct.unpack(end + "2h", hdr[70:74])
+    vox_offset = int(struct.unpack(end + "f", hdr[108:112])[0])
+    slope, inter = struct.unpack(end + "2f", hdr[112:120])
+    if datatype not in _NIFTI_DTYPES:
+        raise ValueError(f"{path}: NIfTI datatype {datatype} unsupported")
+    nd = dim[0]
+    shape = tuple(int(d) for d in dim[1:1 + nd])
+    dt = np.dtype(_NIFTI_DTYPES[datatype]).newbyteorder(end)
+    n = int(np.prod(shape))
+    arr = np.frombuffer(raw, dtype=dt, count=n, offset=max(vox_offset, 352)).reshape(shape[::-1])   # file order: x fastest
+    arr = arr.astype(dt.newbyteorder("="))
+    if slope not in (0.0, 1.0) or (slope != 0.0 and inter != 0.0):
+        arr = arr.astype(np.float32) * np.float32(slope) + np.float32(inter)
+    return arr, bytes(hdr)
+
+
+def write_nifti(path: str, array: np.ndarray, template_header: Optional[bytes] = None, spacing=(1.0, 1.0, 1.0)) -> None:
+    """Write [D,H,W] (z, y, x) as single-file NIfTI-1.  With ``template_header`` the geometry (pixdim, qform / sform) is the
+    template's — the role of ``pred_nii.CopyInformation(template_nii)`` (:648); datatype and dims follow ``array``."""
+    array = np.ascontiguousarray(array)
+    code = _NIFTI_CODES.get(array.dtype.str[1:])
+    if code is None:
+        raise ValueError(f"dtype {array.dtype} has no NIfTI-1 code")
+    if template_header is not None:
+        hdr = bytearray(template_header[:348])
+        end = "<" if struct.unpack("<i", hdr[:4])[0] == 348 else ">"
+    else:
+        hdr, end = bytearray(348), "<"
+        struct.pack_into(end + "i", hdr, 0, 348)
+        struct.pack_into(end + "8f", hdr, 76, 1.0, float(spacing[2]), float(spacing[1]), float(spacing[0]), 1.0, 1.0, 1.0, 1.0)
+        struct.pack_into(end + "h", hdr, 252, 0)           # qform_code
+        struct.pack_into(end + "h", hdr, 254, 1)           # sform_code: scanner-anat, identity scaled by the spacing
+        struct.pack_into(end + "4f", hdr, 280, float(spacing[2]), 0.0, 0.0, 0.0)
+        struct.pack_into(end + "4f", hdr, 296, 0.0, float(spacing[1]), 0.0, 0.0)
+        struct.pack_into(end + "4f", hdr, 312, 0.0, 0.0, float(spacing[0]), 0.0)
+        hdr[123] = 10                                       # xyzt_units: mm + s
+    dims = [array.ndim] + list(array.shape[::-1]) + [1] * (7 - array.ndim)
+    struct.pack_into(end + "8h", hdr, 40, *dims)
+    struct.pack_into(end + "2h", hdr, 70, code, array.dtype.itemsize * 8)
+    struct.pack_into(end + "f", hdr, 108, 352.0)
+    struct.pack_into(end + "2f", hdr, 112, 1.0, 0.0)         # the data are stored unscaled
+    hdr[344:348] = b"n+1\0"
+    data = array.astype(array.dtype.newbyteorder(end), copy=False).tobytes()
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "wb") as f:
+        f.write(bytes(hdr) + b"\0\0\0\0" + data)
+
+
+# ------------------------------------------------------------------------------------------------ metrics
+def _mask(true_array, mask):
+    return mask.astype(bool) if mask is not None else np.ones_like(true_array, dtype=bool)
+
+
+def scale12bit(img):
+    """test_metrics.py:21-26"""
+    return np.clip(((img - np.mean(img)) / (np.std(img) / 400.)) + 2048., 1e-10, 4095)
+
+
+def nrmse(true_array, pred_array, mask=None):
+    """:149-160 — RMSE / (max - min) of the reference inside the mask."""
+    m = _mask(true_array, mask)
+    t, p = true_array[m], pred_array[m]
+    return float(np.sqrt(np.mean((t - p) ** 2)) / (np.max(t) - np.min(t)))
+
+
+def mape(true_array, pred_array, mask=None):
+    """:163-176 (on the 12-bit rescaled images)"""
+    m = _mask(true_array, mask)
+    t, p = scale12bit(true_array[m]), scale12bit(pred_array[m])
+    return float(np.mean(np.fabs(t - p) / np.fabs(t)))
+
+
+def smape(true_array, pred_array, mask=None):
+    """:179-192"""
+    m = _mask(true_array, mask)
+    t, p = scale12bit(true_array[m]), scale12bit(pred_array[m])
+    return float(np.mean(np.fabs(p - t) / (np.fabs(t) + np.fabs(p))))
+
+
+def logac(true_array, pred_array, mask=None):
+    """:195-207"""
+    m = _mask(true_array, mask)
+    t, p = scale12bit(true_array[m]), scale12bit(pred_array[m])
+    return float(np.mean(np.fabs(np.log(p / t))))
+
+
+def medsymac(true_array, pred_array, mask=None):
+    """:211-223 — median symmetric accuracy (Morley 2016)"""
+    m = _mask(true_array, mask)
+    t, p = scale12bit(true_array[m]), scale12bit(pred_array[m])
+    return float(np.exp(np.median(np.fabs(np.log(p / t)))) - 1)
+
+
+def psnr(true_array, pred_array, mask=None):
+    """:378-400 — crop to the mask's bounding box (exclusive upper bound, as the reference slices), zero outside the mask,
+    then 10 log10(data_range^2 / MSE) with data_range = max - min of the cropped reference (skimage's definition)."""
+    m = _mask(true_array, mask)
+    t, p = np.where(m, true_array, 0), np.where(m, pred_array, 0)
+    nz = np.nonzero(m)
+    sl = tuple(slice(int(a.min()), int(a.max())) for a in nz)
+    t, p = t[sl].astype(np.float64), p[sl].astype(np.float64)
+    rng = t.max() - t.min()
+    return float(10.0 * np.log10(rng * rng / np.mean((t - p) ** 2)))

@@ -105,12 +105,13 @@ def test_conv2d_split_structures(ops, prec, structure):
 
 
 WINO_CASES = [
-    # N, H, W, Cin, Cout        (3x3, stride 1; >= 4096 output pixels, even W, Cin % 32 == 0, Cout = 0 or 64 mod 128)
+    # N, H, W, Cin, Cout        (3x3, stride 1; >= 4096 output pixels, W a power of two <= 256, Cin % 32 == 0, Cout = 0 or 64 mod 128)
     (1, 64, 64, 64, 128),        # one full N tile
     (2, 32, 64, 32, 320),        # 128 + 128 + 64: the narrow last N tile; non-square
     (1, 64, 64, 96, 64),         # a single narrow tile, 18 k-tiles
-    (3, 40, 36, 64, 192),        # ragged last M tile (4320 pixels = 16.9 block tiles), W/2 = 18 tiles per row
+    (3, 40, 32, 64, 192),        # ragged last M tile (3840 pixels = 15 block tiles... per sample 1280 px: tiles cross samples)
     (16, 16, 16, 320, 960),      # a 16x16 layer of the network at batch 16 (7 full N tiles + 1 narrow)
+    (1, 128, 256, 32, 128),      # full-width rows: one block = one image row; exercises the folded-upsample variant too
 ]
 
 
@@ -137,12 +138,19 @@ def test_conv2d_winograd_f23(ops, case):
     y2 = ops.conv2d(xc, wc, bc, emb=cu(emb), res=cu(ops.to_nhwc(res)), precision="bf16x6", structure="winograd")
     assert rel_l2(ops.to_nchw(y2), ref2) < PREC_TOL["bf16x6"]
     assert torch.equal(y2, ops.conv2d(xc, wc, bc, emb=cu(emb), res=cu(ops.to_nhwc(res)), precision="bf16x6", structure="winograd"))
+    # nearest x2 folded in front of the convolution (Upsample): the loader reads pixel (h >> 1, w >> 1)
+    if H * W * N >= 4 * 4096:
+        xs = x[:, :, : H // 2, : W // 2].contiguous()
+        refu = F.conv2d(F.interpolate(xs.double(), scale_factor=2, mode="nearest"), w.double(), b.double(), padding=1)
+        yu = ops.conv2d(cu(ops.to_nhwc(xs)), wc, bc, upsample=True, precision="bf16x6", structure="winograd")
+        assert rel_l2(ops.to_nchw(yu), refu) < PREC_TOL["bf16x6"]
 
 
 def test_conv2d_winograd_rejects_ineligible(ops):
     from diffusion_models_dsdiff_amd import _lib
     g = torch.Generator().manual_seed(1)
-    for shp, cout, stride in (((1, 64, 16, 16), 128, 1), ((1, 64, 64, 63), 128, 1), ((1, 64, 64, 64), 96, 1), ((1, 64, 64, 64), 128, 2)):
+    for shp, cout, stride in (((1, 64, 16, 16), 128, 1), ((1, 64, 64, 63), 128, 1), ((1, 64, 114, 36), 128, 1), ((1, 64, 64, 64), 96, 1),
+                              ((1, 64, 64, 64), 128, 2)):
         x = torch.randn(*shp, generator=g)
         w = torch.randn(cout, shp[1], 3, 3, generator=g)
         with pytest.raises(_lib.DsdError):
