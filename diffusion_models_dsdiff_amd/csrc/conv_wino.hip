@@ -194,6 +194,7 @@ __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
     const unsigned char* wt = p.wp + (size_t)tile_n * p.KT * WSTAGE + (size_t)((tid ^ ((tid >> 4) & 1)) * 16);
     auto dma_b = [&](int kt, int so) {
         if (kt >= p.KT) return;
+        if (NT == 2 && wave >= 2) return;   // narrow N tile: rows 64..127 of every plane (waves 2, 3 of each 4 KB round) are never read
         const unsigned char* src = wt + (size_t)kt * WSTAGE;
 #pragma unroll
         for (int i = 0; i < WSTAGE / 4096; ++i)
@@ -254,8 +255,8 @@ __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
         const int ast1 = ast == 2 ? 0 : ast + 1, ast2 = ast1 == 2 ? 0 : ast1 + 1;
         const int st_nxt = A_BASE + ast1 * ASTAGE;
         const int kh1 = kh == 2 ? 0 : kh + 1;
-        dma_b(kt + 1, WSTAGE - so);
-        dma_a(kt + 2, A_BASE + ast2 * ASTAGE);
+        if (!(p.whatif & 2)) dma_b(kt + 1, WSTAGE - so);
+        if (!(p.whatif & 1)) dma_a(kt + 2, A_BASE + ast2 * ASTAGE);
         const unsigned char* bf = Bs + so + frag_off;
         bf16x8 b_cur[3], b_nxt[3];
 #pragma unroll
@@ -271,19 +272,21 @@ __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
                     b_nxt[q] = *reinterpret_cast<const bf16x8*>(bf + (q * 4 + pos1) * WPLANE + j1 * 32 * 32);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (u == 0) {
-                rd(1, st_cur, kh, d1l, d1h);
-                rd(2, st_cur, kh, d2l, d2h);
+            if (!(p.whatif & 4)) {
+                if (u == 0) {
+                    rd(1, st_cur, kh, d1l, d1h);
+                    rd(2, st_cur, kh, d2l, d2h);
+                }
+                if (u == NT - 1) split8x3(d1l + d2l, d1h + d2h, af[1]);
+                if (u == NT) rd(3, st_cur, kh, xl, xh);
+                if (u == 2 * NT - 1) split8x3(d2l - d1l, d2h - d1h, af[2]);
+                if (u == 2 * NT) {
+                    rd(0, st_nxt, kh1, yl, yh);
+                    rd(2, st_nxt, kh1, d2l, d2h);
+                }
+                if (u == 3 * NT - 1) split8x3(d1l - xl, d1h - xh, af[3]);
+                if (u == 4 * NT - 1) split8x3(yl - d2l, yh - d2h, af[0]);
             }
-            if (u == NT - 1) split8x3(d1l + d2l, d1h + d2h, af[1]);
-            if (u == NT) rd(3, st_cur, kh, xl, xh);
-            if (u == 2 * NT - 1) split8x3(d2l - d1l, d2h - d1h, af[2]);
-            if (u == 2 * NT) {
-                rd(0, st_nxt, kh1, yl, yh);
-                rd(2, st_nxt, kh1, d2l, d2h);
-            }
-            if (u == 3 * NT - 1) split8x3(d1l - xl, d1h - xh, af[3]);
-            if (u == 4 * NT - 1) split8x3(yl - d2l, yh - d2h, af[0]);
             mfma6(af[pos], b_cur, acc[pos][j]);
 #pragma unroll
             for (int q = 0; q < 3; ++q) b_cur[q] = b_nxt[q];
@@ -442,6 +445,16 @@ bool conv2d_wino_shape_ok(const ConvArgs& a) {
     if (xb >= 0xFFFFFF00ll) return false;
     const int64_t M = (int64_t)a.N * OH * OW;
     return M >= 4096 && M < (1ll << 31);
+}
+
+// At least two full rounds of workgroups over the 256 CUs; smaller grids stay on the direct / split-K kernels (measured:
+// 16 x 32x32 x 640->640 = 320 workgroups runs at 185 TF/s here against 224 direct, 16 x 64x64 = 1280 workgroups 275 vs 224).
+bool conv2d_wino_worthwhile(const ConvArgs& a) {
+    if (!conv2d_wino_shape_ok(a)) return false;
+    static const int min_blocks = getenv("DSD_WINO_MIN_BLOCKS") ? atoi(getenv("DSD_WINO_MIN_BLOCKS")) : 512;
+    const int64_t M = (int64_t)a.N * a.H * a.W * (a.ups ? 4 : 1);
+    const int64_t blocks = ((M / 2 + WTILES - 1) / WTILES) * ((a.Cout + WBROWS - 1) / WBROWS);
+    return blocks >= min_blocks;
 }
 
 int conv2d_wino_stats_chunks(const ConvArgs& a) {

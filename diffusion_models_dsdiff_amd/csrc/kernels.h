@@ -64,6 +64,7 @@ void pack_ohwi(const float* w_oihw, float* w_ohwi, int Cout, int Cin, int ks, hi
 // conv_wino.hip: 3x3 stride-1 convolution as F(2,3) along the width (1.5x fewer MFMAs), bf16x6 arithmetic
 bool conv2d_wino_shape_ok(const ConvArgs& a);      // could run there if it had packed weights
 bool conv2d_wino_eligible(const ConvArgs& a);      // shape_ok and a.w_wino present
+bool conv2d_wino_worthwhile(const ConvArgs& a);    // shape_ok and a grid big enough to beat the direct kernel (the planner's rule)
 size_t wino_packed_bytes(int Cout, int Cin);
 void wino_pack_weights(const float* w_ohwi, int Cout, int Cin, void* packed, hipStream_t s);
 void conv2d_wino(const ConvArgs& a, hipStream_t s);

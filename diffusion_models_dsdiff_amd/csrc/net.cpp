@@ -668,7 +668,7 @@ struct Builder {
             a.precision = hd->precision;
             a.ovf = f16 ? hd->ovf : nullptr;
             // 3x3 stride-1 layers with enough tiles: F(2,3)-along-W kernel (conv_wino.hip), transformed weights packed once
-            if (hd->use_winograd && conv2d_wino_shape_ok(a)) {
+            if (hd->use_winograd && conv2d_wino_worthwhile(a)) {
                 const std::string wkey = name + "#wino";
                 auto wi = hd->wsplit.find(wkey);
                 if (wi == hd->wsplit.end()) {

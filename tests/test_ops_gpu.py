@@ -109,7 +109,7 @@ WINO_CASES = [
     (1, 64, 64, 64, 128),        # one full N tile
     (2, 32, 64, 32, 320),        # 128 + 128 + 64: the narrow last N tile; non-square
     (1, 64, 64, 96, 64),         # a single narrow tile, 18 k-tiles
-    (3, 40, 32, 64, 192),        # ragged last M tile (3840 pixels = 15 block tiles... per sample 1280 px: tiles cross samples)
+    (3, 44, 32, 64, 192),        # ragged last block (2112 tiles = 16.5 blocks), blocks straddle samples
     (16, 16, 16, 320, 960),      # a 16x16 layer of the network at batch 16 (7 full N tiles + 1 narrow)
     (1, 128, 256, 32, 128),      # full-width rows: one block = one image row; exercises the folded-upsample variant too
 ]
