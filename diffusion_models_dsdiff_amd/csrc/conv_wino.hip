@@ -125,8 +125,9 @@ __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
         const int cpx = (int)gridDim.x >> 3;
         if (L < (cpx << 3)) L = (L & 7) * cpx + (L >> 3);   // consecutive tiles on one XCD (its L2)
     }
-    const int tile_n = L % p.tiles_n;
-    const int tile_m = L / p.tiles_n;
+    // whatif & 8: N tiles outermost (every CU of an XCD streams the same 2.4 MB of packed weights: L2-resident)
+    const int tile_n = (p.whatif & 8) ? L / p.tiles_m : L % p.tiles_n;
+    const int tile_m = (p.whatif & 8) ? L % p.tiles_m : L / p.tiles_n;
     const int t0 = tile_m * WTILES;
     const int n0 = tile_n * WBROWS;
     if (tid < 4) *reinterpret_cast<f32x4*>(Bs + Z_OFF + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -382,7 +383,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoP p) {
         const int cpx = (int)gridDim.x >> 3;
         if (L < (cpx << 3)) L = (L & 7) * cpx + (L >> 3);
     }
-    const bool narrow = (L % p.tiles_n) == p.tiles_n - 1 && (p.Cout % WBROWS) != 0;   // uniform: last N tile of a Cout = 64 (mod 128) layer
+    const int tn = (p.whatif & 8) ? L / p.tiles_m : L % p.tiles_n;
+    const bool narrow = tn == p.tiles_n - 1 && (p.Cout % WBROWS) != 0;   // uniform: last N tile of a Cout = 64 (mod 128) layer
     if (narrow)
         wino_body<2>(p, Bs);
     else
