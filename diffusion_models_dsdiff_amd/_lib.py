@@ -131,7 +131,7 @@ def lib() -> C.CDLL:
                                 C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
     L.dsd_op_conv2d_prec.argtypes = [f32p, i32, i32, i32, i32, f32p, f32p, i32, i32, i32, i32, f32p, f32p, i32, f32p, vp]
     L.dsd_op_group_norm.argtypes = [f32p, i32, i32, i32, f32p, f32p, C.c_float, i32, f32p, vp]
-    L.dsd_op_qkv_attention.argtypes = [f32p, i32, i32, i32, i32, i32, f32p, vp]
+    L.dsd_op_qkv_attention.argtypes = [f32p, i32, i32, i32, i32, i32, i32, f32p, vp]
     L.dsd_op_timestep_embedding.argtypes = [vp, i32, i32, i32, f32p, f32p, vp]
     L.dsd_op_linear.argtypes = [f32p, i32, i32, f32p, f32p, i32, i32, f32p, vp]
     L.dsd_op_gaussian_sample.argtypes = [f32p, f32p, C.c_uint64, i32, i32, i32, i32, f32p, vp]

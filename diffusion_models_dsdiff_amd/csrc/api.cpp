@@ -638,7 +638,7 @@ int dsd_op_group_norm(const float* x, int N, int HW, int C, const float* gamma, 
     DSD_CATCH
 }
 
-int dsd_op_qkv_attention(const float* qkv, int N, int T, int C, int heads, int new_order, float* out, void* stream) {
+int dsd_op_qkv_attention(const float* qkv, int N, int T, int C, int heads, int new_order, int split, float* out, void* stream) {
     DSD_TRY
     DSD_CHECK(heads > 0 && C % heads == 0, "C=%d not divisible by heads=%d", C, heads);
     const int d = C / heads;
@@ -654,6 +654,7 @@ int dsd_op_qkv_attention(const float* qkv, int N, int T, int C, int heads, int n
         a.q_hs = a.k_hs = a.v_hs = 3 * d;
     }
     a.out = out;
+    a.split = split != 0;
     attention(a, (hipStream_t)stream);
     DSD_CATCH
 }

@@ -179,7 +179,9 @@ __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
     const unsigned rowpitch = (unsigned)p.IW * (unsigned)p.Cin * 4u;
     auto dma_a = [&](int kt, int stage_off) {
         if (kt >= p.KT) return;
-        const int cc = kt / 3, kh = kt - cc * 3;
+        // k-tile order: 32-channel chunk, filter row, 16-channel half — the two 64-byte halves of a pixel's 128-byte line are
+        // fetched by CONSECUTIVE tiles (the first brings the line into L2, the second hits it)
+        const int c32 = kt / 6, sub = kt - c32 * 6, kh = sub >> 1, cc = c32 * 2 + (sub & 1);
         const int soff = __builtin_amdgcn_readfirstlane(cc * 64);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -249,13 +251,14 @@ __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
     //   during position 2:  U_3 = d1 - d3 -> af[3];  d0, d2 of the NEXT tile are read (its stage is already visible)
     //   during position 3:  U_0 = d0 - d2 of the next tile -> af[0]
     // and at the top of the tile the DMAs of the weights of tile kt+1 and of the activations of tile kt+2 go out.
-    int kh = 0, ast = 0;   // filter row of tile kt; index (0..2) of its activation stage
+    int sub6 = 0, ast = 0;   // position of tile kt inside its group of 6 (kh = sub6 >> 1); index (0..2) of its activation stage
     for (int kt = 0; kt < p.KT; ++kt) {
         const int so = (kt & 1) * WSTAGE;
         const int st_cur = A_BASE + ast * ASTAGE;
         const int ast1 = ast == 2 ? 0 : ast + 1, ast2 = ast1 == 2 ? 0 : ast1 + 1;
         const int st_nxt = A_BASE + ast1 * ASTAGE;
-        const int kh1 = kh == 2 ? 0 : kh + 1;
+        const int sub61 = sub6 == 5 ? 0 : sub6 + 1;
+        const int kh = sub6 >> 1, kh1 = sub61 >> 1;
         if (!(p.whatif & 2)) dma_b(kt + 1, WSTAGE - so);
         if (!(p.whatif & 1)) dma_a(kt + 2, A_BASE + ast2 * ASTAGE);
         const unsigned char* bf = Bs + so + frag_off;
@@ -294,7 +297,7 @@ __device__ __forceinline__ void wino_body(const WinoP& p, unsigned char* Bs) {
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();   // DMAs issued at the top have landed (vmcnt(0) before the barrier); every wave left this tile's stages
-        kh = kh1;
+        sub6 = sub61;
         ast = ast1;
     }
 
@@ -392,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(WinoP p) {
 }
 
 // w (OHWI fp32: [Cout][3][3][Cin]) -> transformed, split and packed:
-//   out[tile_n][kt = cc*3 + kh][piece][pos][row][16]  bf16,   co = tile_n*128 + row,  ci = cc*16 + k
+//   out[tile_n][kt = (cc/2)*6 + kh*2 + cc%2][piece][pos][row][16]  bf16,   co = tile_n*128 + row,  ci = cc*16 + k
 //   V_0 = g0, V_1 = (g0+g1+g2)/2, V_2 = (g0-g1+g2)/2, V_3 = g2   (g_kw = w[co][kh][kw][ci]; fp64, one rounding to fp32)
 __global__ void wino_pack_kernel(const float* __restrict__ w, int Cout, int Cin, unsigned short* __restrict__ out) {
     const int64_t total = (int64_t)Cout * 3 * Cin;
@@ -406,7 +409,7 @@ __global__ void wino_pack_kernel(const float* __restrict__ w, int Cout, int Cin,
         const float v[4] = {(float)g0, (float)((g0 + g1 + g2) * 0.5), (float)((g0 - g1 + g2) * 0.5), (float)g2};
         const int tile_n = co / WBROWS, row = co - tile_n * WBROWS;
         const int cc = ci / 16, k = ci - cc * 16;
-        const int kt = cc * 3 + kh;
+        const int kt = (cc >> 1) * 6 + kh * 2 + (cc & 1);   // the kernel's k-tile order: (32-channel chunk, kh, 16-channel half)
         unsigned short* base = out + ((int64_t)tile_n * KT + kt) * (WSTAGE / 2);
 #pragma unroll
         for (int pos = 0; pos < 4; ++pos) {

@@ -102,6 +102,7 @@ struct AttnArgs {
     int N = 0, Tq = 0, Tk = 0, heads = 0, d = 0;
     float scale_q = 1.f, scale_k = 1.f, scale_s = 1.f;
     float* out = nullptr;  // [N][Tq][ldo], head h at +h*d
+    int split = 0;         // 1: both products on the bf16 matrix cores with operands split into 3 bf16 pieces (bf16x6), 0: fp32 MFMA
 };
 void attention(const AttnArgs& a, hipStream_t s);
 

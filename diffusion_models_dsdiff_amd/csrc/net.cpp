@@ -846,6 +846,7 @@ struct Builder {
             AttnArgs aa;
             aa.N = x.n; aa.Tq = T; aa.Tk = T; aa.heads = heads; aa.d = d;
             aa.ldq = aa.ldk = aa.ldv = 3 * C; aa.ldo = C;
+            aa.split = hd->precision != PREC_F32;
             const float scale = 1.f / std::sqrt(std::sqrt((float)d));  // openaimodel.py:547
             aa.scale_q = aa.scale_k = scale;
             int qo, ko, vo;
@@ -995,6 +996,7 @@ struct Builder {
         aa.N = x.n; aa.Tq = x.hw(); aa.Tk = c.hw(); aa.heads = heads; aa.d = d;
         aa.ldq = aa.ldk = aa.ldv = aa.ldo = inner;
         aa.q_hs = aa.k_hs = aa.v_hs = d;
+        aa.split = hd->precision != PREC_F32;
         aa.scale_s = 1.f / std::sqrt((float)d);
         const size_t qo = q.off, ko = k.off, vo = v.off, ao = a.off;
         dsd_handle* h = hd;
@@ -1428,6 +1430,7 @@ void build_dit(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
             aa.N = B; aa.Tq = T; aa.Tk = T; aa.heads = c.heads; aa.d = hdim;
             aa.ldq = aa.ldk = aa.ldv = 3 * D; aa.ldo = D;
             aa.q_hs = aa.k_hs = aa.v_hs = hdim;
+            aa.split = hd->precision != PREC_F32;
             aa.scale_q = 1.f / std::sqrt((float)hdim);
             const size_t qo = qkv.off, ao = a.off;
             const double fl = 4.0 * B * c.heads * (double)T * T * hdim;

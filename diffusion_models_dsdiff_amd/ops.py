@@ -46,10 +46,11 @@ def group_norm(x_nhwc, gamma, beta, eps=1e-5, silu=False):
     return y
 
 
-def qkv_attention(qkv_ntc, heads, new_order=True):
+def qkv_attention(qkv_ntc, heads, new_order=True, split=False):
+    """split: bf16x6 arithmetic (operands as 3 bf16 pieces, 6 products) instead of the fp32 matrix cores."""
     N, T, C3 = qkv_ntc.shape
     a = torch.empty((N, T, C3 // 3), device=qkv_ntc.device, dtype=torch.float32)
-    check(lib().dsd_op_qkv_attention(dptr(qkv_ntc), N, T, C3 // 3, heads, int(new_order), dptr(a), stream_ptr()))
+    check(lib().dsd_op_qkv_attention(dptr(qkv_ntc), N, T, C3 // 3, heads, int(new_order), int(split), dptr(a), stream_ptr()))
     return a
 
 

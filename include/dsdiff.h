@@ -291,8 +291,10 @@ int dsd_conv_plan(int N, int H, int W, int Cin, int Cout, int ks, int stride, in
 /* GroupNorm(32, C, eps) [+ SiLU] on x[N,HW,C]. */
 int dsd_op_group_norm(const float* x, int N, int HW, int C, const float* gamma, const float* beta, float eps,
                       int silu, float* y, void* stream);
-/* QKVAttention / QKVAttentionLegacy (openaimodel.py:496-555) on qkv[N,T,3C] -> a[N,T,C]. */
-int dsd_op_qkv_attention(const float* qkv, int N, int T, int C, int heads, int new_order, float* a, void* stream);
+/* QKVAttention / QKVAttentionLegacy (openaimodel.py:496-555) on qkv[N,T,3C] -> a[N,T,C].  split = 0: both products on
+ * the fp32 matrix cores (what DSD_PREC_F32 runs); 1: operands split exactly into three bf16 pieces, six bf16 MFMA products
+ * each (what every other mode runs); the softmax is fp32 either way. */
+int dsd_op_qkv_attention(const float* qkv, int N, int T, int C, int heads, int new_order, int split, float* a, void* stream);
 /* timestep_embedding (util.py:161-181): t[N] (int64 or fp32) -> [N,dim].  freqs (device, [dim/2], may be NULL): the
  * frequency table as the caller's own fp32 exp evaluates it (what dsd_set_timestep_freqs installs in a model handle);
  * with it the sin/cos arguments are bit-identical to the reference's. */

@@ -235,14 +235,18 @@ def test_group_norm_golden(ops):
 
 @pytest.mark.parametrize("N,T,C,heads,new", [(2, 64, 64, 4, True), (2, 64, 64, 2, False), (1, 4, 64, 2, True),
                                              (1, 1024, 128, 4, True), (1, 144, 96, 2, True), (2, 200, 128, 2, True),
-                                             (1, 256, 96, 3, False), (1, 70, 256, 2, True)])
+                                             (1, 256, 96, 3, False), (1, 70, 256, 2, True), (2, 330, 144, 2, True),
+                                             (1, 4096, 128, 2, True)])
 def test_qkv_attention_vs_oracle(ops, N, T, C, heads, new):
     g = torch.Generator().manual_seed(T + C)
     qkv = torch.randn(N, 3 * C, T, generator=g)
     ref = attn_ref64(qkv, heads, new)                                  # [N, C, T]
     assert rel_l2(O.qkv_attention(qkv, heads, new), ref) < 1e-6        # the oracle agrees with the fp64 evaluation
-    a = ops.qkv_attention(cu(qkv.permute(0, 2, 1)), heads, new)        # [N, T, C]
-    assert rel_l2(a.permute(0, 2, 1), ref) < 3e-6
+    for split in (False, True):                                        # fp32 MFMA kernel / bf16x6 kernel (3 bf16 pieces, 6 products)
+        a = ops.qkv_attention(cu(qkv.permute(0, 2, 1)), heads, new, split=split)        # [N, T, C]
+        err = rel_l2(a.permute(0, 2, 1), ref)
+        print(f"attention N={N} T={T} C={C} heads={heads} split={split}: rel-L2 vs fp64 {err:.3e}")
+        assert err < 3e-6, split
 
 
 def test_attention_online_softmax_rescale(ops):
@@ -252,8 +256,9 @@ def test_attention_online_softmax_rescale(ops):
     qkv = torch.randn(N, 3 * C, T, generator=g)
     qkv[0, C:2 * C, 200] *= 30.0      # spike key 200 (4th LDS stage)
     ref = attn_ref64(qkv, heads, True)
-    a = ops.qkv_attention(cu(qkv.permute(0, 2, 1)), heads, True)
-    assert rel_l2(a.permute(0, 2, 1), ref) < 3e-6
+    for split in (False, True):
+        a = ops.qkv_attention(cu(qkv.permute(0, 2, 1)), heads, True, split=split)
+        assert rel_l2(a.permute(0, 2, 1), ref) < 3e-6, split
 
 
 def test_timestep_embedding(ops):
