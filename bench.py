@@ -48,6 +48,14 @@ F_LIVE_PER_SLICE_STEP = 5.5427e12   # algorithmic FLOPs per 256^2 
 HEADLINE = {"batch": 16, "size": 256, "model_channels": None}
 # MFMA products issued per fp32 multiply-add of the convolution, and the matrix peak of the dtype they are issued in
 PASSES = {"f32": 1, "bf16x6": 6, "bf16x3": 3, "f16x3": 3}
+# The F(2,3)-along-W kernel multiplies 4 transformed values where the direct form multiplies 6: per ALGORITHMIC (direct-form)
+# FLOP it issues 2/3 of the MFMA work.  `achieved` must count what the matrix pipes really execute.
+WINOGRAD_MFMA_FRACTION = 2.0 / 3.0
+
+
+def mfma_passes(kernel, precision):
+    p = float(PASSES[precision])
+    return p * WINOGRAD_MFMA_FRACTION if kernel.startswith("conv_wino") else p
 ISSUED_DTYPE = {"f32": "f32", "bf16x6": "bf16", "bf16x3": "bf16", "f16x3": "f16"}
 
 
@@ -71,6 +79,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-modes", action="store_true", help="do not also time the other arithmetic modes")
     ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph of a step instead of launching every "
                                                          "kernel from the host (measured equal at batch 16, no gain at batch 1)")
+    ap.add_argument("--winograd", action="store_true", help="bf16x6 only: the F(2,3)-along-W kernel for the large 3x3 layers "
+                                                            "(include/dsdiff.h: dsd_set_winograd); otherwise a separate line in `modes`")
     return ap.parse_args(argv)
 
 
@@ -218,6 +228,7 @@ class GpuLeg:
         self.model = model = instantiate_from_config(uc)
         model.set_precision(args.precision)
         model.use_graph(args.graph)
+        model.winograd(args.winograd)
         synth_weights_(model, 2024)
         self.n_params = sum(p.numel() for p in model.parameters())
         # one-off weight distribution: rank 0's parameters broadcast as ONE packed blob over RCCL/xGMI
@@ -291,7 +302,7 @@ class GpuLeg:
         dk, dv = max(rep.items(), key=lambda kv: kv[1]["ms"])
         calls = max(dv["calls"], 1)
         alg = dv["flops"] / (dv["ms"] / 1e3) / 1e12          # algorithmic (fp32-equivalent 2*MAC) TFLOP/s of its launches
-        passes = PASSES[precision]
+        passes = mfma_passes(dk, precision)
         peak = issued_peak(precision)
         # HBM bytes per launch from the newest committed PMC passes of this same command (tools/profile_round.sh; separate
         # --pmc runs, FETCH_SIZE x2 on gfx950, KiB -> bytes): counters cannot be read live, so the figure carries its
@@ -331,7 +342,8 @@ class GpuLeg:
             "launches_per_step": dv["calls"] // max(runs, 1), "avg_launch_ms": round(dv["ms"] / calls, 4),
             "flops_per_launch": dv["flops"] / calls, "share_of_step_time": round(dv["ms"] / tot_ms, 4),
             "whole_step_algorithmic_tflops": res["whole_step_tflops"],
-            "whole_step_frac_issued": round(res["whole_step_tflops"] * passes / peak, 4),
+            "whole_step_frac_issued": round(sum(v["flops"] * mfma_passes(k, precision) for k, v in rep.items())
+                                            / (tot_ms / 1e3) / 1e12 / peak, 4),
             "whole_step_frac_vs_fp32_mfma_peak": round(res["whole_step_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)}
         kern = {}
         for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
@@ -422,6 +434,15 @@ def run_rank(args):
                 "ms_per_step": r["ms_per_step"], "value": r["value"], "executed_flops_per_step": r["info"]["flops"],
                 "note": "same output up to fp32 rounding; 2 of the 4 encoder streams have all-zero input in the 1->1-channel case and are "
                         "computed at batch 1 (SURVEY.md 7: must be reported separately)"}
+            # separate line: the large 3x3 layers on the F(2,3)-along-W kernel (1.5x fewer MFMAs; conv_wino.hip)
+            if not args.winograd and args.precision == "bf16x6":
+                model.winograd(True)
+                r = leg.measure(args.precision, 3, 1, 0 if args.no_profile else 1, barrier, reduce_max)
+                model.winograd(False)
+                modes["bf16x6+winograd"] = {k: r[k] for k in ("ms_per_step", "value", "whole_step_tflops")}
+                if r["roofline"]:
+                    modes["bf16x6+winograd"]["dominant_kernel"] = {k: r["roofline"][k] for k in (
+                        "kernel", "achieved", "peak", "frac", "algorithmic_tflops", "avg_launch_ms", "mfma_products_per_fp32_product")}
             # separate line: the network evaluation of a step replayed as ONE captured hipGraph instead of ~800 host launches
             if not args.graph:
                 model.use_graph(True)
@@ -496,7 +517,7 @@ def run_rank(args):
                       "workspace_GiB": round(info["workspace_bytes"] / 2 ** 30, 2), "launches_per_step": info["launches"],
                       "executed_flops_per_step": info["flops"],
                       "survey_flops_per_step": F_LIVE_PER_SLICE_STEP * B,
-                      "hip_graph": bool(args.graph) and not stub,
+                      "hip_graph": bool(args.graph) and not stub, "winograd": bool(args.winograd) and not stub,
                       "launched_by": "self (bench.py --gpus N)" if os.environ.get("DSD_BENCH_LAUNCHED_BY_PARENT") else
                                      ("torch.distributed.run" if world > 1 else "single process"),
                       "backend": backend if world > 1 else None,

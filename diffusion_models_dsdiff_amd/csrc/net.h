@@ -129,7 +129,7 @@ struct dsd_handle {
     // replayed on the caller's stream while plan + bound pointers stay the same
     hipEvent_t param_ev = nullptr;   // recorded after every dsd_set_param on the stream it used
     int use_graph = 0;
-    int use_winograd = 1;    // bf16x6 only: 3x3 stride-1 convolutions as F(2,3) along the width (conv_wino.hip)
+    int use_winograd = 0;    // bf16x6 only, opt-in: 3x3 stride-1 convolutions as F(2,3) along the width (conv_wino.hip)
     int fuse_gn_stats = 1;   // GroupNorm statistics from the producing kernel's epilogue (0: always the standalone pass)
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;

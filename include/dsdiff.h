@@ -106,12 +106,15 @@ int dsd_set_share_zero_streams(dsd_handle* h, int on);
  * in the epilogue of the kernel that writes the tensor and the separate statistics pass over HBM disappears
  * (openaimodel.py:264-284: "fused GroupNorm" of the north star).  0 = always run the standalone pass (A/B, tests). */
 int dsd_set_fuse_gn_stats(dsd_handle* h, int on);
-/* bf16x6 mode only (ON by default): 3x3 stride-1 convolutions with >= 4096 output pixels, an even width, Cin % 16 == 0 and
- * Cout % 32 == 0 run as Winograd F(2,3) ALONG THE WIDTH — 4 instead of 6 products per pair of outputs and filter row,
- * i.e. 1.5x fewer MFMAs.  The input transform (sums / differences of neighbouring pixels) is done in fp32, the weight
- * transform once in fp64, and both operands are then split into three bf16 pieces exactly as in the direct kernel, so
- * every operand still carries 24 significant bits; the result differs from the direct form by an fp32 re-association of
- * the convolution sum (measured, tests/test_ops_gpu.py).  0 = the direct kernels everywhere. */
+/* bf16x6 mode only, OFF by default: 3x3 stride-1 convolutions whose grid fills the chip at least twice (>= 512 workgroups),
+ * with an output width that is a power of two <= 256, Cin % 32 == 0 and Cout = 0 or 64 (mod 128), run as Winograd F(2,3)
+ * ALONG THE WIDTH — 4 instead of 6 products per pair of outputs and filter row, i.e. 1.5x fewer MFMAs.  The input transform
+ * (sums / differences of neighbouring pixels) is done in fp32, the weight transform once in fp64, and both operands are then
+ * split into three bf16 pieces exactly as in the direct kernel, so every operand still carries 24 significant bits; the
+ * result differs from the direct form by an fp32 re-association of the convolution sum (measured: 0.75x the direct
+ * kernel's error against fp64, tests/test_ops_gpu.py).  Opt-in because it is only 6-20 % faster than the direct kernel on
+ * the layers it takes (its operand feeding costs what the saved MFMAs gain: conv_wino.hip header) — 2 % on a whole
+ * denoising step — and stays below the 300 TF/s go / no-go set for it. */
 int dsd_set_winograd(dsd_handle* h, int on);
 /* 0 if every parameter has been set, else -1 with the first missing name in dsd_last_error(). */
 int dsd_params_ready(dsd_handle* h);
