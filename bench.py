@@ -160,11 +160,30 @@ def cpu_baseline(unet_params, sd, H, W, budget_s):
     return rep, x, t, y
 
 
-def latest_pmc():
-    """Newest committed PMC summary (profiles/rNN_pmc.json, tools/profile_round.sh) and its provenance block."""
+def kernel_symbol(kind):
+    """Plan kind (dsd_profile_get, e.g. "conv_bf16x6<5>", "conv_bf16x3<4>/r128+splitk", "conv_mfma<5>") -> the kernel symbol
+    the rocprofv3 summaries list it under (spaces removed), or None."""
+    m = re.match(r"conv_(bf16x6|bf16x3|f16x3|mfma)<(\d)>(/r128|/staged)?", kind)
+    if kind.startswith("conv_wino"):
+        return "conv_wino_kernel"
+    if not m:
+        return {"gn_silu_apply": "affine_act_kernel<1>", "gn_apply": "affine_act_kernel<0>", "gn_stats": "gn_stats_kernel",
+                "attention": "attention"}.get(kind)
+    mode, nt, st = m.group(1), m.group(2), m.group(3)
+    if mode == "mfma":
+        return f"conv_mfma_buf_kernel<{nt}>"
+    np_, f16 = {"bf16x6": ("3", "false"), "bf16x3": ("2", "false"), "f16x3": ("2", "true")}[mode]
+    if st == "/staged":
+        return f"conv_split_kernel<{nt},{np_},{f16}>"
+    return f"conv_split_ad_kernel<{nt},{np_},{f16},{'1' if st == '/r128' else '2'}>"
+
+
+def latest_pmc(precision="bf16x6"):
+    """Newest committed PMC summary of this arithmetic mode (profiles/rNN_pmc[_<mode>].json, tools/profile_round.sh)."""
     best, bn = None, -1
-    for p in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")):
-        m = re.match(r"r(\d+)_pmc\.json$", os.path.basename(p))
+    suffix = "" if precision == "bf16x6" else "_" + precision
+    for p in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc*.json")):
+        m = re.match(r"r(\d+)_pmc" + re.escape(suffix) + r"\.json$", os.path.basename(p))
         if m and int(m.group(1)) > bn:
             best, bn = p, int(m.group(1))
     return best
@@ -308,17 +327,17 @@ class GpuLeg:
         # --pmc runs, FETCH_SIZE x2 on gfx950, KiB -> bytes): counters cannot be read live, so the figure carries its
         # provenance and is dropped when the summary does not contain the kernel this run found dominant.
         traffic, source = None, None
-        pmc = latest_pmc()
+        pmc = latest_pmc(precision)
         if pmc:
             try:
                 d = json.load(open(pmc))
                 meta = d.get("_meta", {})
-                want = dk.split("(")[0].replace(" ", "")
+                want = kernel_symbol(dk)
                 best = 0.0
                 for kname, e in d.items():
-                    if kname == "_meta" or not isinstance(e, dict):
+                    if kname == "_meta" or not isinstance(e, dict) or want is None:
                         continue
-                    if kname.replace("dsd::", "").replace(" ", "").startswith(want) and e.get("total_us_under_pmc", 0) > best \
+                    if want in kname.replace(" ", "") and e.get("total_us_under_pmc", 0) > best \
                             and meta.get("precision", "bf16x6") == precision:
                         best = e["total_us_under_pmc"]
                         traffic = e.get("hbm_bytes_per_launch")

@@ -239,3 +239,30 @@ def test_conv_plan_invariants():
     assert _conv_plan(16, 16, 16, 960, 960, precision=1)[0] == 0        # ... staged structure at M = 4096
     assert _conv_plan(16, 256, 256, 320, 320, precision=2 | 16)[0] == 1 # forced structures are honoured
     assert _conv_plan(16, 256, 256, 320, 320, precision=2 | 32)[0] == 0
+
+
+def test_wrapped_model_hands_the_original_timesteps_to_the_network():
+    """_wrap_model (the role of respace.py:116-128): loop index -> timestep of the ORIGINAL process, int64 when the
+    timesteps are not rescaled, fp32 (x 1000 / T_orig) otherwise — the same values the device loop uploads."""
+    import torch
+    seen = {}
+
+    def net(x, t, **kw):
+        seen["t"], seen["kw"] = t, kw
+        return x
+
+    for rescale in (False, True):
+        d = create_gaussian_diffusion(steps=1000, timestep_respacing="50", rescale_timesteps=rescale, parameterization="v")
+        tmap = np.asarray(sorted(space_timesteps(1000, "50")), dtype=np.int64)
+        w = d._wrap_model(net)
+        assert d._wrap_model(w) is w
+        idx = torch.tensor([0, 7, 49])
+        w(torch.zeros(3, 1), idx, c_concat=[1])
+        assert seen["kw"] == {"c_concat": [1]}
+        if rescale:
+            assert seen["t"].dtype == torch.float32
+            want = tmap[idx.numpy()].astype(np.float32) * np.float32(1000.0 / 1000)
+            assert np.array_equal(seen["t"].numpy(), want)
+        else:
+            assert seen["t"].dtype == torch.int64 and np.array_equal(seen["t"].numpy(), tmap[idx.numpy()])
+        assert np.array_equal(d._model_timestep_values()[idx.numpy()], seen["t"].numpy().astype(np.float32))

@@ -313,7 +313,7 @@ def test_full_size_vs_oracle(full_model):
 
 def test_winograd_mode_full_size_vs_oracle(full_model):
     """dsd_set_winograd (opt-in, bf16x6): the large 3x3 layers on the F(2,3)-along-W kernel.  At 256x256 every layer down to
-    64x64 takes it at batch 2; the network output must hold the same 1e-5 against the oracle as the direct kernels, the
+    128x128 takes it at batch 2 (>= 512 workgroups); the network output must hold the same 1e-5 against the oracle as the direct kernels, the
     kernel must really be in the plan, and switching it off again must restore the direct result bit for bit."""
     m, cfg, sd = full_model
     x = randn((2, 2, 256, 256), 95)
@@ -326,7 +326,7 @@ def test_winograd_mode_full_size_vs_oracle(full_model):
     y_w = m._run(x.cuda(), t.cuda(), want_feats=False)[0]
     rep, _ = m.profile_report()
     m.profile(False)
-    assert "conv_wino_bf16x6" in rep and rep["conv_wino_bf16x6"]["calls"] >= 40, sorted(rep)
+    assert "conv_wino_bf16x6" in rep and rep["conv_wino_bf16x6"]["calls"] >= 20, sorted(rep)   # 24 layers at batch 2
     e_w, e_d = rel_l2(y_w[1:], yo), rel_l2(y_direct[1:], yo)
     print(f"full-size forward 256x256 bf16x6: winograd rel-L2 {e_w:.3e}, direct {e_d:.3e}")
     assert e_w < 1e-5 and e_d < 1e-5
