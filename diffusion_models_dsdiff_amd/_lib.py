@@ -20,7 +20,7 @@ PRED_EPS, PRED_X0, PRED_V = 0, 1, 2
 PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
 (BLOCK_RES, BLOCK_ATTN, BLOCK_UPSAMPLE, BLOCK_DOWNSAMPLE, BLOCK_DISENTANGLE, BLOCK_SE, BLOCK_CROSSATTN,
  BLOCK_FF_GEGLU, BLOCK_BASIC_TRANSFORMER, BLOCK_SPATIAL_TRANSFORMER, BLOCK_VAE_ENCODER, BLOCK_VAE_DECODER,
- BLOCK_DIT) = range(13)
+ BLOCK_DIT, BLOCK_UNET) = range(14)
 
 # every symbol include/dsdiff.h declares (tests/test_abi.py checks the header against this list)
 EXPORTS = [

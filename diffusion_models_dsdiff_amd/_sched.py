@@ -78,7 +78,13 @@ def run_device_loop(unet, sched: Schedule, x_T: torch.Tensor, cond: torch.Tensor
 def sampler_update(sched: Schedule, k: int, model_out: torch.Tensor, x: torch.Tensor,
                    noise: Optional[torch.Tensor], seed: int = 0, want_x0: bool = False):
     """One fused update (dsd_op_sampler_update); x is updated in place."""
-    B, _, H, W = x.shape
+    B, Cx, H, W = x.shape
+    if Cx > 1:
+        # multi-channel states (latents): the update is elementwise, so [B,C,H,W] is B*C one-channel images — except for
+        # the learned-range variance, whose model output interleaves mean and variance channels per sample
+        if sched.c.learned_range:
+            raise NotImplementedError("learned-range variance on multi-channel states is not on the sampling hot path")
+        B = B * Cx
     x0 = torch.empty_like(x) if want_x0 else None
     check(lib().dsd_op_sampler_update(C.byref(sched.c), k, dptr(model_out.float().contiguous()), dptr(x),
                                       dptr(noise.float().contiguous()) if noise is not None else None,

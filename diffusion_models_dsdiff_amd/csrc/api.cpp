@@ -167,8 +167,9 @@ int dsd_set_param(dsd_handle* h, const char* name, const float* src, const int64
 
 int dsd_set_timestep_freqs(dsd_handle* h, const float* freqs_host, int n) {
     DSD_TRY
-    DSD_CHECK(h && freqs_host && (!h->is_block || h->block_kind == DSD_BLOCK_DIT), "null argument / handle without a timestep embedding");
-    const int want = h->is_block ? 128 : h->cfg.model_channels / 2;   // DiT: frequency_embedding_size 256 (DiT_models.py:31)
+    DSD_CHECK(h && freqs_host && (!h->is_block || h->block_kind == DSD_BLOCK_DIT || h->block_kind == DSD_BLOCK_UNET),
+              "null argument / handle without a timestep embedding");
+    const int want = h->block_kind == DSD_BLOCK_DIT ? 128 : h->cfg.model_channels / 2;   // DiT: frequency_embedding_size 256 (DiT_models.py:31)
     DSD_CHECK(n == want, "expected %d frequencies, got %d", want, n);
     set_device(h->device);
     if (!h->freqs) DSD_HIP(hipMalloc((void**)&h->freqs, (size_t)n * sizeof(float)));

@@ -79,11 +79,12 @@ Layer mk_res(int cin, int cout, bool up = false, bool down = false) {
 }
 
 // model.py:282-515
-Spec build_spec(const dsd_config& c) {
+Spec build_spec(const dsd_config& c, bool plain = false) {
     Spec s;
     const int mc = c.model_channels;
     DSD_CHECK(c.n_levels >= 1 && c.n_levels <= DSD_MAX_LEVELS, "channel_mult must have 1..%d entries", DSD_MAX_LEVELS);
-    DSD_CHECK(c.in_channels == 1, "in_channels must be 1: every stream of DSUnetModel.forward receives one plane (model.py:654-663)");
+    DSD_CHECK(plain || c.in_channels == 1, "in_channels must be 1: every stream of DSUnetModel.forward receives one plane (model.py:654-663)");
+    DSD_CHECK(c.in_channels >= 1 && mc >= 32 && mc % 32 == 0 && c.out_channels >= 1, "bad channel counts");
     int num_heads = c.num_heads, num_heads_upsample = c.num_heads_upsample;
     if (num_heads_upsample == -1) num_heads_upsample = num_heads;
     const int nhc = c.num_head_channels;
@@ -302,6 +303,44 @@ void p_dit(dsd_handle* h, const DitCfg& c) {
     p_lin(h, "final_layer.adaLN_modulation.1", c.D, 2 * c.D, true, 1);
 }
 
+// ---- plain single-stream UNetModel (ldm/modules/diffusionmodules/openaimodel.py:571-958), the denoiser of the latent path.
+// iargs: in_channels, model_channels, out_channels, num_heads, num_head_channels, num_heads_upsample, use_scale_shift_norm,
+//        resblock_updown, use_new_attention_order, legacy, n_levels, channel_mult[..], num_res_blocks[..] (per level),
+//        n_attention_resolutions, attention_resolutions[..]
+dsd_config unet_cfg_from_iargs(const std::vector<int32_t>& a) {
+    DSD_CHECK(a.size() >= 12, "UNetModel handle needs >= 12 integer arguments");
+    dsd_config c{};
+    c.in_channels = a[0]; c.model_channels = a[1]; c.out_channels = a[2];
+    c.num_heads = a[3]; c.num_head_channels = a[4]; c.num_heads_upsample = a[5];
+    c.use_scale_shift_norm = a[6]; c.resblock_updown = a[7]; c.use_new_attention_order = a[8]; c.legacy = a[9];
+    c.n_levels = a[10];
+    DSD_CHECK(c.n_levels >= 1 && c.n_levels <= DSD_MAX_LEVELS && (int)a.size() >= 12 + 2 * c.n_levels, "UNetModel: bad channel_mult");
+    for (int i = 0; i < c.n_levels; ++i) {
+        c.channel_mult[i] = a[11 + i];
+        c.num_res_blocks[i] = a[11 + c.n_levels + i];
+    }
+    c.n_attention_resolutions = a[11 + 2 * c.n_levels];
+    DSD_CHECK(c.n_attention_resolutions >= 0 && c.n_attention_resolutions <= DSD_MAX_LEVELS &&
+              (int)a.size() >= 12 + 2 * c.n_levels + c.n_attention_resolutions, "UNetModel: bad attention_resolutions");
+    for (int i = 0; i < c.n_attention_resolutions; ++i) c.attention_resolutions[i] = a[12 + 2 * c.n_levels + i];
+    return c;
+}
+void p_plain_unet(dsd_handle* h) {
+    const Spec s = build_spec(h->cfg, true);
+    const bool film = h->cfg.use_scale_shift_norm;
+    p_lin(h, "time_embed.0", h->cfg.model_channels, s.ted);
+    p_lin(h, "time_embed.2", s.ted, s.ted);
+    for (size_t bi = 0; bi < s.input_blocks.size(); ++bi)
+        for (size_t li = 0; li < s.input_blocks[bi].size(); ++li)
+            p_layer(h, "input_blocks." + std::to_string(bi) + "." + std::to_string(li), s.input_blocks[bi][li], s.ted, film);
+    for (size_t li = 0; li < s.middle.size(); ++li) p_layer(h, "middle_block." + std::to_string(li), s.middle[li], s.ted, film);
+    for (size_t bi = 0; bi < s.output_blocks.size(); ++bi)
+        for (size_t li = 0; li < s.output_blocks[bi].size(); ++li)
+            p_layer(h, "output_blocks." + std::to_string(bi) + "." + std::to_string(li), s.output_blocks[bi][li], s.ted, film);
+    p_norm(h, "out.0", s.final_ch);
+    p_conv(h, "out.2", h->cfg.model_channels, h->cfg.out_channels, 3);
+}
+
 void p_vae_res(dsd_handle* h, const std::string& p, int cin, int cout) {
     p_norm(h, p + ".norm1", cin);
     p_conv(h, p + ".conv1", cin, cout, 3);
@@ -427,6 +466,10 @@ void dsd::net_declare_params(dsd_handle* h) {
                 break;
             }
             case DSD_BLOCK_DIT: p_dit(h, dit_cfg(a)); break;
+            case DSD_BLOCK_UNET:
+                h->cfg = unet_cfg_from_iargs(a);
+                p_plain_unet(h);
+                break;
             case DSD_BLOCK_VAE_ENCODER: p_vae_encoder(h, vae_cfg(a)); break;
             case DSD_BLOCK_VAE_DECODER: p_vae_decoder(h, vae_cfg(a)); break;
             default: fail("unknown block kind %d", h->block_kind);
@@ -1342,6 +1385,130 @@ void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats, bool 
     b.release(emb_all);
 }
 
+// --------------------------------------------------------------------------------- UNetModel.forward (openaimodel.py:926-958)
+// x: NCHW [B, in_channels, H, W] (latents, with the `concat` conditioning already appended), aux = timesteps [B] fp32.
+void build_plain_unet(Builder& b, int C, int H, int W, int aux_len) {
+    dsd_handle* hd = b.hd;
+    const dsd_config& cfg = hd->cfg;
+    const Spec sp = build_spec(cfg, true);
+    const int B = b.B;
+    const int nds = cfg.n_levels - 1;
+    DSD_CHECK(C == cfg.in_channels, "UNetModel: input has %d channels, expected %d", C, cfg.in_channels);
+    DSD_CHECK(H % (1 << nds) == 0 && W % (1 << nds) == 0, "H=%d, W=%d must be multiples of %d (down/up-sampling + skip concat)", H, W, 1 << nds);
+    DSD_CHECK(aux_len == 1, "UNetModel: timesteps missing");
+    // ---- timestep embedding MLP + all emb_layers as ONE GEMM (openaimodel.py:939-940; :222-228,273)
+    const int mc = cfg.model_channels, ted = sp.ted, etot = (int)hd->emb_total;
+    Tn temb = b.alloc(B, 1, 1, mc), e1 = b.alloc(B, 1, 1, ted), emb = b.alloc(B, 1, 1, ted), emb_all = b.alloc(B, 1, 1, etot);
+    {
+        const size_t to = temb.off, e1o = e1.off, eo = emb.off, ao = emb_all.off;
+        const float *w0 = b.W("time_embed.0.weight"), *b0 = b.W("time_embed.0.bias");
+        const float *w2 = b.W("time_embed.2.weight"), *b2 = b.W("time_embed.2.bias");
+        const float* wall = reinterpret_cast<const float*>(hd->slab + hd->emb_w_off);
+        const float* ball = reinterpret_cast<const float*>(hd->slab + hd->emb_b_off);
+        const double fl = 2.0 * B * ((double)mc * ted + (double)ted * ted + (double)ted * etot);
+        b.plan.flops += fl;
+        b.op([=](hipStream_t s) {
+            float* tp = reinterpret_cast<float*>(hd->arena + to);
+            float* e1p = reinterpret_cast<float*>(hd->arena + e1o);
+            float* ep = reinterpret_cast<float*>(hd->arena + eo);
+            float* ap = reinterpret_cast<float*>(hd->arena + ao);
+            timestep_embedding(hd->io.aux, 1, B, mc, tp, s, hd->freqs);
+            linear(tp, B, mc, mc, w0, b0, ted, ACT_NONE, e1p, ted, s);
+            linear(e1p, B, ted, ted, w2, b2, ted, ACT_SILU, ep, ted, s);
+            linear(ep, B, ted, ted, wall, ball, etot, ACT_SILU, ap, etot, s);
+        }, 4, "time_embed_mlp", fl);
+    }
+    b.release(temb); b.release(e1); b.release(emb);
+    std::unordered_map<std::string, int64_t> emb_col;
+    {
+        int64_t col = 0;
+        for (const auto& p : hd->params)
+            if (p.region == 2) {
+                emb_col[p.name.substr(0, p.name.size() - std::strlen(".emb_layers.1.bias"))] = col;
+                col += p.numel;
+            }
+    }
+    auto embs_of = [&](const std::string& prefix, const std::vector<Layer>& layers) {
+        std::vector<EmbRef> out;
+        for (size_t li = 0; li < layers.size(); ++li)
+            if (layers[li].kind == L_RES) {
+                EmbRef e;
+                e.arena_off = emb_all.off;
+                e.col = emb_col.at(prefix + "." + std::to_string(li));
+                e.stride = etot;
+                e.valid = true;
+                out.push_back(e);
+            }
+        return out;
+    };
+    // ---- encoder: h = module(h, emb); hs.append(h)   (:946-948)
+    Tn x = b.import_ext(0, B, H, W, C, /*from_nchw=*/true);
+    std::vector<Tn> hs;
+    Tn cur = x;
+    for (size_t bi = 0; bi < sp.input_blocks.size(); ++bi) {
+        const std::string pre_ = "input_blocks." + std::to_string(bi);
+        auto embs = embs_of(pre_, sp.input_blocks[bi]);
+        size_t ei = 0;
+        Tn nxt = b.block(pre_, sp.input_blocks[bi], cur, /*keep_input=*/true, embs, ei);
+        hs.push_back(nxt);
+        cur = nxt;
+    }
+    b.release(x);
+    // ---- middle (:949)
+    Tn h;
+    {
+        auto me = embs_of("middle_block", sp.middle);
+        size_t ei = 0;
+        h = b.block("middle_block", sp.middle, hs.back(), /*keep_input=*/true, me, ei);
+    }
+    // ---- decoder: h = cat([h, hs.pop()]); h = module(h, emb)   (:950-952); a block's last convolution writes h straight into
+    // the first channels of the next concat buffer
+    auto block_out = [&](const std::vector<Layer>& layers, int c, int hh, int ww, int* oc, int* oh, int* ow) {
+        *oc = c; *oh = hh; *ow = ww;
+        for (const Layer& L : layers) {
+            if (L.kind == L_RES || L.kind == L_CONV) *oc = L.cout;
+            if (L.kind == L_UP || (L.kind == L_RES && L.up)) { *oh *= 2; *ow *= 2; }
+            if (L.kind == L_DOWN || (L.kind == L_RES && L.down)) { *oh /= 2; *ow /= 2; }
+        }
+    };
+    Tn c2 = b.alloc(B, h.h, h.w, h.c + hs.back().c);
+    b.avg(&h, 1, 1.f, c2, 0, ACT_NONE, /*want_stats=*/true);
+    b.release(h);
+    for (size_t bi = 0; bi < sp.output_blocks.size(); ++bi) {
+        Tn sk = hs.back();
+        hs.pop_back();
+        DSD_CHECK(sk.h == c2.h && sk.w == c2.w, "decoder skip shape mismatch at output_blocks.%zu", bi);
+        const int hc = c2.c - sk.c;
+        b.avg(&sk, 1, 1.f, c2, hc, ACT_NONE, /*want_stats=*/true);
+        b.release(sk);
+        const bool last = bi + 1 == sp.output_blocks.size();
+        Tn next;
+        if (!last) {
+            int oc, oh, ow;
+            block_out(sp.output_blocks[bi], c2.c, c2.h, c2.w, &oc, &oh, &ow);
+            next = b.alloc(B, oh, ow, oc + hs.back().c);
+        }
+        const std::string pre_ = "output_blocks." + std::to_string(bi);
+        auto de = embs_of(pre_, sp.output_blocks[bi]);
+        size_t ei = 0;
+        Tn out = b.block(pre_, sp.output_blocks[bi], c2, /*keep_input=*/false, de, ei, -1, last ? nullptr : &next);
+        if (last) {
+            h = out;
+        } else {
+            next.st[0] = out.st[0];
+            c2 = next;
+        }
+    }
+    // ---- out = Conv3x3(SiLU(GN(h)))   (:901-905,957)
+    Tn a = b.gn_act("out.0", h, ACT_SILU);
+    b.release(h);
+    Tn y = b.conv("out.2", a, cfg.out_channels, 3);
+    b.release(a);
+    b.export_out(y, /*to_nchw=*/true);
+    b.release(y);
+    b.release(emb_all);
+}
+
 // --------------------------------------------------------------------------------- DiT.forward (DiT_models.py:224-243)
 // x: NCHW [B, in_channels, S, S] (the caller concatenates `cond`), aux = t [B] fp32, aux2 = y [B] int64 (optional).
 void build_dit(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
@@ -1485,6 +1652,10 @@ void build_block(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
     const bool token = kind == DSD_BLOCK_CROSSATTN || kind == DSD_BLOCK_FF_GEGLU || kind == DSD_BLOCK_BASIC_TRANSFORMER;
     if (kind == DSD_BLOCK_DIT) {
         build_dit(b, C, H, W, aux_len, aux_len2);
+        return;
+    }
+    if (kind == DSD_BLOCK_UNET) {
+        build_plain_unet(b, C, H, W, aux_len);
         return;
     }
     Tn x = b.import_ext(0, B, H, W, C, !token);

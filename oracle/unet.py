@@ -357,6 +357,25 @@ def unet_forward(cfg: UNetConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, 
     return _Net(cfg, sd).forward(x, timesteps)
 
 
+@torch.no_grad()
+def plain_unet_forward(cfg: UNetConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, timesteps: torch.Tensor):
+    """UNetModel.forward (ldm/modules/diffusionmodules/openaimodel.py:926-958): the single-stream denoiser of the latent
+    path (no class embedding, no spatial transformer)."""
+    net = _Net(cfg, sd)
+    t_emb = timestep_embedding(timesteps, cfg.model_channels)
+    emb = F.linear(t_emb, net.p("time_embed.0.weight"), net.p("time_embed.0.bias"))
+    emb = F.linear(F.silu(emb), net.p("time_embed.2.weight"), net.p("time_embed.2.bias"))
+    h, hs = x.float(), []
+    for bi, layers in enumerate(net.spec["input_blocks"]):
+        h = net.block(f"input_blocks.{bi}", layers, h, emb)
+        hs.append(h)
+    h = net.block("middle_block", net.spec["middle"], h, emb)
+    for bi, layers in enumerate(net.spec["output_blocks"]):
+        h = torch.cat([h, hs.pop()], dim=1)
+        h = net.block(f"output_blocks.{bi}", layers, h, emb)
+    return net.conv("out.2", F.silu(net.gn("out.0", h)))
+
+
 def block_forward(cfg: UNetConfig, sd, kind: str, prefix: str, L: dict, x, emb=None):
     """Single block entry for op-level tests."""
     net = _Net(cfg, sd)

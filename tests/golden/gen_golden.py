@@ -529,6 +529,28 @@ def gen_vae():
     save("vae", **out)
 
 
+LATENT_UNET = dict(image_size=8, in_channels=8, model_channels=32, out_channels=4, num_res_blocks=1, attention_resolutions=[2, 1],
+                   channel_mult=[1, 2], num_head_channels=16, use_spatial_transformer=False, legacy=False, use_checkpoint=False)
+LATENT_UNET2 = dict(image_size=16, in_channels=16, model_channels=64, out_channels=4, num_res_blocks=2, attention_resolutions=[4],
+                    channel_mult=[1, 2, 2], num_heads=2, use_spatial_transformer=False, legacy=True, use_scale_shift_norm=True,
+                    resblock_updown=True, use_new_attention_order=True, use_checkpoint=False)
+
+
+def gen_latent_unet():
+    """The plain UNetModel (ldm/modules/diffusionmodules/openaimodel.py:571-958) that denoises the VAE latents in the latent
+    path: two small configurations (the yaml's flavour: num_head_channels, legacy False; and FiLM + resblock_updown + num_heads)."""
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    out = {}
+    for key, params, seed, shp in (("lu", LATENT_UNET, 400, (2, 8, 16, 16)), ("lu2", LATENT_UNET2, 401, (2, 16, 16, 24))):
+        m = UNetModel(**params)
+        ps = load_synth(m, seed)
+        x = randn(shp, seed + 1)
+        out.update({f"{key}_cfg": json.dumps(params), f"{key}_params": ps, f"{key}_seed": seed, f"{key}_xshape": np.asarray(shp),
+                    f"{key}_int_y": m(x, torch.tensor([999, 17])).numpy(),
+                    f"{key}_float_y": m(x, torch.tensor([499.5, 20.0])).numpy()})
+    save("latent_unet", **out)
+
+
 def gen_temb():
     """timestep_embedding (ldm/modules/diffusionmodules/util.py:161-181) with the frequency table AS THIS HOST's torch
     evaluates it stored beside the outputs: torch's vectorised fp32 exp differs by 1 ulp between CPU ISAs (AVX2 / AVX-512),
@@ -550,6 +572,6 @@ def gen_temb():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "ops", "xattn", "model", "loops", "loops2", "dpm", "temb", "vae"]
+    which = sys.argv[1:] or ["schedules", "ops", "xattn", "model", "loops", "loops2", "dpm", "temb", "vae", "latent_unet"]
     for w in which:
         globals()["gen_" + w]()

@@ -113,3 +113,29 @@ def test_vae_parameter_tables_match_reference_names():
             L.dsd_destroy(h)
         ref = {n: tuple(s) for n, s in json.loads(str(g[key + "_params"]))}
         assert got == ref
+
+
+def test_plain_unet_parameter_table_matches_reference_names():
+    """Table-only DSD_BLOCK_UNET handles carry exactly the reference UNetModel's state_dict (tests/golden/latent_unet.npz)."""
+    import json
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "latent_unet.npz"))
+    L = _lib.lib()
+    for key in ("lu", "lu2"):
+        p = json.loads(str(g[key + "_cfg"]))
+        cm = p["channel_mult"]
+        nrb = p["num_res_blocks"]
+        nrb = [nrb] * len(cm) if isinstance(nrb, int) else nrb
+        ar = p["attention_resolutions"]
+        ia = [p["in_channels"], p["model_channels"], p["out_channels"], p.get("num_heads", -1), p.get("num_head_channels", -1), -1,
+              int(p.get("use_scale_shift_norm", False)), int(p.get("resblock_updown", False)),
+              int(p.get("use_new_attention_order", False)), int(p.get("legacy", True)), len(cm)] + cm + nrb + [len(ar)] + ar
+        h = C.c_void_p()
+        _lib.check(L.dsd_block_create(_lib.BLOCK_UNET, (C.c_int32 * len(ia))(*ia), len(ia), -1, C.byref(h)))
+        got = {}
+        name, shape, ndim = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+        for i in range(L.dsd_param_count(h)):
+            _lib.check(L.dsd_param_info(h, i, C.byref(name), shape, C.byref(ndim)))
+            got[name.value.decode()] = tuple(shape[k] for k in range(ndim.value))
+        L.dsd_destroy(h)
+        assert got == {n: tuple(s) for n, s in json.loads(str(g[key + "_params"]))}

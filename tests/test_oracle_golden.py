@@ -333,3 +333,16 @@ def test_vae_oracle_matches_reference_fixtures(key):
     assert rel_l2(V.decode(cfg, sd, zin), g[key + "_decode"]) < 2e-6
     zraw = randn((xshape[0], cfg.z_channels, xshape[2] // f, xshape[3] // f), seed + 40)
     assert rel_l2(V.decoder(cfg, sd, zraw), g[key + "_dec_raw"]) < 2e-6
+
+
+@pytest.mark.parametrize("key", ["lu", "lu2"])
+def test_plain_unet_oracle_matches_reference_fixtures(key):
+    """oracle.unet.plain_unet_forward against the reference's UNetModel (tests/golden/latent_unet.npz)."""
+    import json
+    g = golden("latent_unet")
+    params = json.loads(str(g[key + "_cfg"]))
+    cfg = unet.UNetConfig.from_params(params)
+    sd = fixture_params(g, key)
+    x = randn(tuple(int(v) for v in g[key + "_xshape"]), int(g[key + "_seed"]) + 1)
+    assert rel_l2(unet.plain_unet_forward(cfg, sd, x, torch.tensor([999, 17])), g[key + "_int_y"]) < 2e-6
+    assert rel_l2(unet.plain_unet_forward(cfg, sd, x, torch.tensor([499.5, 20.0])), g[key + "_float_y"]) < 2e-6
