@@ -63,7 +63,7 @@ class UNetModel(_Block):
     @torch.no_grad()
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
         """openaimodel.py:926-958."""
-        assert (y is not None) == (self.num_classes is not None), \\
+        assert (y is not None) == (self.num_classes is not None), \
             "must specify y if and only if the model is class-conditional"
         if not x.is_cuda:
             raise _lib.DsdError("UNetModel runs on the MI355X only (no CPU fallback)")
