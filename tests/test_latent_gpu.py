@@ -43,7 +43,7 @@ def test_unet_model_golden(key):
     with pytest.raises(_lib.DsdError):
         m(randn((1, params["in_channels"] + 1, 16, 16), 1).cuda(), torch.tensor([1]).cuda())
     with pytest.raises(_lib.DsdError):
-        m(randn((1, params["in_channels"], 18, 16), 1).cuda(), torch.tensor([1]).cuda())
+        m(randn((1, params["in_channels"], 17, 16), 1).cuda(), torch.tensor([1]).cuda())
 
 
 def test_latent_pipeline_encode_sample_decode():
