@@ -85,6 +85,10 @@ void gn_stats(const float* x, int N, int HW, int C, double* partial, int nchunk,
 // s1 (optional: p == nullptr) the rest — a concatenated tensor has one source per part.
 void gn_finalize(const GnSrc& s0, const GnSrc& s1, int N, int HW, int C, const float* gamma, const float* beta,
                  float eps, const float* film, int film_stride, float* scale, float* shift, hipStream_t s);
+// whole GroupNorm32 (+ FiLM, + activation) of a small map in one launch: one workgroup per (group, sample)
+bool gn_small_ok(int HW, int C);
+void gn_small(const float* x, int N, int HW, int C, const float* gamma, const float* beta, float eps, const float* film,
+              int film_stride, int act, float* y, hipStream_t s);
 // avg_into (misc.hip) on [N][HW][C] sources + the per-column statistics of what it wrote: partial [N][gn_nchunks(HW,C)][C][2]
 void avg_into_stats(const float* a, const float* b, const float* c, const float* d, float div, int N, int HW, int C,
                     float* dst, int dstC, int coff, int act, int bmask, double* partial, int nchunk, hipStream_t s);

@@ -784,6 +784,23 @@ struct Builder {
     // ---- GroupNorm32 (+SiLU, + FiLM) : stats, finalize, apply
     Tn gn_act(const std::string& name, const Tn& x, int act, float eps = 1e-5f, const EmbRef* film = nullptr) {
         const int HW = x.hw(), C = x.c, N = x.n;
+        if (hd->fuse_gn_stats && gn_small_ok(HW, C)) {   // small map: statistics + finalize + apply in ONE launch
+            Tn y = alloc(x.n, x.h, x.w, x.c);
+            const float* gamma = W(name + ".weight");
+            const float* beta = W(name + ".bias");
+            DSD_CHECK(hd->PP(name + ".weight").numel == C, "norm %s: %lld channels, graph expects %d", name.c_str(),
+                      (long long)hd->PP(name + ".weight").numel, C);
+            const size_t xoff = x.off, yoff = y.off;
+            EmbRef e;
+            if (film) e = *film;
+            dsd_handle* h = hd;
+            op([=](hipStream_t s) {
+                const float* fp = e.valid ? reinterpret_cast<const float*>(h->arena + e.arena_off) + e.col : nullptr;
+                gn_small(reinterpret_cast<const float*>(h->arena + xoff), N, HW, C, gamma, beta, eps, fp, e.stride, act,
+                         reinterpret_cast<float*>(h->arena + yoff), s);
+            }, 1, act == ACT_SILU ? "gn_silu_small" : "gn_small", 0.0, 12.0 * N * HW * C);
+            return y;
+        }
         // statistics that came with the tensor (convolution epilogue / concat kernel), else a pass of our own
         const bool have = x.st[0].valid() && x.st[0].c0 == 0 &&
                           (x.st[0].c == C || (x.st[1].valid() && x.st[1].c0 == x.st[0].c && x.st[0].c + x.st[1].c == C));
