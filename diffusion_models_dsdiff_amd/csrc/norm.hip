@@ -210,23 +210,50 @@ void gn_finalize(const GnSrc& s0, const GnSrc& s1, int N, int HW, int C, const f
 // Small maps (a group's HW x C/32 values fit a workgroup's reach): ONE launch per GroupNorm instead of statistics +
 // finalize + apply — one workgroup per (group, sample) sums its values in fp64, then normalises them (second read from L2).
 // At batch 1 the three-launch form of the 8x8 ... 32x32 layers is pure launch latency (~4.5 ms of a 38 ms step).
-template <int ACT>
+// V = values per load (2 when the group width is even: 8-byte loads; else 1).  Loads are issued U at a time before they are
+// consumed (a dependent chain of single loads made the first version latency-bound: 27 us per launch at batch 1).
+template <int ACT, int V>
 __global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__ x, int HW, int C, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, const float* __restrict__ film,
                                                        int film_stride, float* __restrict__ y) {
+    constexpr int U = 8;
     __shared__ double red[4][2];
     __shared__ float mean_s, rstd_s;
     const int g = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cpg = C / GN_GROUPS;
+    const int cpg = C / GN_GROUPS, cv = cpg / V;
     const float* xb = x + (int64_t)n * HW * C + g * cpg;
     float* yb = y + (int64_t)n * HW * C + g * cpg;
-    const int items = HW * cpg;
+    const int items = HW * cv;                      // V-wide items: (pixel, channel pair)
+    auto off = [&](int i) {
+        const int p = i / cv, c = i - p * cv;
+        return (int64_t)p * C + c * V;
+    };
     double s = 0.0, q = 0.0;
-    for (int i = tid; i < items; i += 256) {
-        const int p = i / cpg, c = i - p * cpg;
-        const double v = xb[(int64_t)p * C + c];
-        s += v;
-        q = fma(v, v, q);
+    for (int i0 = tid; i0 < items; i0 += 256 * U) {
+        float v[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256;
+#pragma unroll
+            for (int k = 0; k < V; ++k) v[u][k] = 0.f;
+            if (i < items) {
+                if (V == 2) {
+                    const float2 t = *reinterpret_cast<const float2*>(xb + off(i));
+                    v[u][0] = t.x;
+                    v[u][V - 1] = t.y;
+                } else {
+                    v[u][0] = xb[off(i)];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const double d = v[u][k];     // padding items add exact zeros
+                s += d;
+                q = fma(d, d, q);
+            }
     }
     for (int o = 32; o > 0; o >>= 1) {
         s += __shfl_xor(s, o);
@@ -240,7 +267,7 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__
     if (tid == 0) {
         const double a = (red[0][0] + red[1][0]) + (red[2][0] + red[3][0]);
         const double b = (red[0][1] + red[1][1]) + (red[2][1] + red[3][1]);
-        const double cnt = (double)items;
+        const double cnt = (double)HW * cpg;
         const double mean = a / cnt;
         double var = b / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -249,18 +276,48 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__
     }
     __syncthreads();
     const float mean = mean_s, rstd = rstd_s;
-    for (int i = tid; i < items; i += 256) {
-        const int p = i / cpg, c = i - p * cpg, ch = g * cpg + c;
-        float sc = rstd * gamma[ch];                 // the same scale / shift form as gn_finalize + affine_act
-        float sh = beta[ch] - mean * sc;
+    auto coef = [&](int ch, float& sc, float& sh) {   // the same scale / shift form as gn_finalize + affine_act
+        sc = rstd * gamma[ch];
+        sh = beta[ch] - mean * sc;
         if (film) {
             const float f = 1.f + film[(int64_t)n * film_stride + ch];
             sc *= f;
             sh = sh * f + film[(int64_t)n * film_stride + C + ch];
         }
-        float v = fmaf(xb[(int64_t)p * C + c], sc, sh);
-        if (ACT == ACT_SILU) v = silu_f(v);
-        yb[(int64_t)p * C + c] = v;
+    };
+    for (int i0 = tid; i0 < items; i0 += 256 * U) {
+        float v[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256;
+            if (i < items) {
+                if (V == 2) {
+                    const float2 t = *reinterpret_cast<const float2*>(xb + off(i));
+                    v[u][0] = t.x;
+                    v[u][V - 1] = t.y;
+                } else {
+                    v[u][0] = xb[off(i)];
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * 256;
+            if (i >= items) continue;
+            const int p = i / cv, c = (i - p * cv) * V;
+            float o[V];
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                float sc, sh;
+                coef(g * cpg + c + k, sc, sh);
+                o[k] = fmaf(v[u][k], sc, sh);
+                if (ACT == ACT_SILU) o[k] = silu_f(o[k]);
+            }
+            if (V == 2)
+                *reinterpret_cast<float2*>(yb + (int64_t)p * C + c) = make_float2(o[0], o[V - 1]);
+            else
+                yb[(int64_t)p * C + c] = o[0];
+        }
     }
 }
 
@@ -269,10 +326,15 @@ bool gn_small_ok(int HW, int C) { return C % GN_GROUPS == 0 && (int64_t)HW * (C 
 void gn_small(const float* x, int N, int HW, int C, const float* gamma, const float* beta, float eps, const float* film,
               int film_stride, int act, float* y, hipStream_t s) {
     if ((int64_t)N * HW * C == 0) return;
-    if (act == ACT_SILU)
-        hipLaunchKernelGGL(gn_small_kernel<ACT_SILU>, dim3(GN_GROUPS, N), dim3(256), 0, s, x, HW, C, gamma, beta, eps, film, film_stride, y);
-    else
-        hipLaunchKernelGGL(gn_small_kernel<ACT_NONE>, dim3(GN_GROUPS, N), dim3(256), 0, s, x, HW, C, gamma, beta, eps, film, film_stride, y);
+    const bool v2 = (C / GN_GROUPS) % 2 == 0;   // group start and pixel stride are then multiples of 8 bytes
+    const dim3 grid(GN_GROUPS, N), block(256);
+#define DSD_GNS(A, VV) hipLaunchKernelGGL((gn_small_kernel<A, VV>), grid, block, 0, s, x, HW, C, gamma, beta, eps, film, film_stride, y)
+    if (act == ACT_SILU) {
+        if (v2) DSD_GNS(ACT_SILU, 2); else DSD_GNS(ACT_SILU, 1);
+    } else {
+        if (v2) DSD_GNS(ACT_NONE, 2); else DSD_GNS(ACT_NONE, 1);
+    }
+#undef DSD_GNS
     check_launch("gn_small");
 }
 
