@@ -15,6 +15,8 @@
 // pass is y = act(x*scale + shift): 1 read + 1 write of the tensor.
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace dsd {
 
 static constexpr int GN_GROUPS = 32;
@@ -209,7 +211,8 @@ void gn_finalize(const GnSrc& s0, const GnSrc& s1, int N, int HW, int C, const f
 
 // Small maps (a group's HW x C/32 values fit a workgroup's reach): ONE launch per GroupNorm instead of statistics +
 // finalize + apply — one workgroup per (group, sample) sums its values in fp64, then normalises them (second read from L2).
-// At batch 1 the three-launch form of the 8x8 ... 32x32 layers is pure launch latency (~4.5 ms of a 38 ms step).
+// An experiment for the batch-1 latency (the three-launch form of the 8x8 ... 32x32 layers looked like pure launch latency);
+// measured no gain, see gn_small_ok.
 // V = values per load (2 when the group width is even: 8-byte loads; else 1).  Loads are issued U at a time before they are
 // consumed (a dependent chain of single loads made the first version latency-bound: 27 us per launch at batch 1).
 template <int ACT, int V>
@@ -321,7 +324,13 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const float* __restrict__
     }
 }
 
-bool gn_small_ok(int HW, int C) { return C % GN_GROUPS == 0 && (int64_t)HW * (C / GN_GROUPS) <= 32768; }
+// Measured (bench.py kernels table, same kernels otherwise): batch 1 — 38.6 ms per step with it, 38.0 without; batch 16 — the
+// small maps' GroupNorm work 3.0 ms with it against ~2.5 ms as statistics-from-epilogue + finalize + apply.  672 instead of
+// 854 launches per step, but the step is not launch-bound, so it stays OFF: DSD_GN_SMALL=1 enables it.
+bool gn_small_ok(int HW, int C) {
+    static const bool on = getenv("DSD_GN_SMALL") != nullptr;
+    return on && C % GN_GROUPS == 0 && (int64_t)HW * (C / GN_GROUPS) <= 32768;
+}
 
 void gn_small(const float* x, int N, int HW, int C, const float* gamma, const float* beta, float eps, const float* film,
               int film_stride, int act, float* y, hipStream_t s) {
