@@ -478,11 +478,16 @@ __device__ __forceinline__ void split8(f32x4 lo, f32x4 hi, typename Elt<F16>::v8
 // RB = 32-row blocks per wave.  RB = 1: block tile 128 x 32*NT, two workgroups per CU.  RB = 2: block tile 256 x 32*NT,
 // ONE workgroup per CU (accumulators alone are 2*NT*16 registers): every weight fragment read from LDS feeds two MFMA
 // groups, which halves the LDS traffic per MFMA, and a k-tile carries twice the MFMAs per barrier.
-template <int NT, int NP, bool F16, int RB>
+// DMA = the weight tile goes global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) instead of through registers: no staging
+// registers (32) and no ds_write_b128 (8 per thread and tile) in the MFMA stream.  The LDS image is then lane-linear — rows
+// of 64 B without padding — and the bank-conflict-free order is an XOR swizzle of the four 16-byte chunks of a row with
+// (row >> 2) & 3, applied on the source address and on the fragment reads (as in conv_wino.hip).
+template <int NT, int NP, bool F16, int RB, bool DMA = false>
 __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(SplitP p) {
     typedef typename Elt<F16>::v8 bf16x8;
     constexpr int BROWS = NT * 32;
-    constexpr int B_PLANE = BROWS * RSB;
+    constexpr int RS = DMA ? 64 : RSB;              // LDS row stride of a weight plane
+    constexpr int B_PLANE = BROWS * RS;
     constexpr int NBL = (BROWS * 4 * NP + 255) / 256;
     // Two LDS stages for the weight tile: tile kt+1 is written into stage (kt+1)&1 while tile kt is read from the other
     // one, so ONE barrier per k-tile is enough (stage (kt+1)&1 was last read for tile kt-1, and every wave has passed the
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
     // staging round write there instead of branching on the exec mask.
     constexpr int STAGE = NP * B_PLANE;
     static_assert((2 * STAGE + 4096) * (RB == 1 ? 2 : 1) <= 160 * 1024, "both weight stages of the resident workgroups must fit the LDS");
-    __shared__ __attribute__((aligned(16))) unsigned char Bs[2 * STAGE + 256 * 16];
+    __shared__ __attribute__((aligned(1024))) unsigned char Bs[2 * STAGE + 256 * 16];
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
@@ -555,12 +560,14 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         const int rem = q - piece * (BROWS * 4);
         // 8 consecutive lanes (one ds_write_b128 bank group) write rows r and r+4: with the 80-byte row stride their two
         // 64-byte segments are 320 B = 64 (mod 128) apart, i.e. all 32 banks exactly once (rows r, r+1 overlap on 4 banks)
-        const int ch = rem & 3;
-        const int row = (rem >> 5) * 8 + ((rem >> 3) & 3) + 4 * ((rem >> 2) & 1);
+        // DMA: chunk q lands at LDS byte 16 q = (piece, row = rem >> 2, physical chunk rem & 3), which holds the logical
+        // chunk (rem & 3) ^ ((row >> 2) & 3) of that row
+        const int ch = DMA ? ((rem & 3) ^ ((rem >> 4) & 3)) : (rem & 3);
+        const int row = DMA ? (rem >> 2) : (rem >> 5) * 8 + ((rem >> 3) & 3) + 4 * ((rem >> 2) & 1);
         const int n = n0 + row;
         const bool ok = piece < NP && n < p.Cout;
         b_voff[i] = ok ? (unsigned)piece * p.w_plane_bytes + ((unsigned)n * (unsigned)p.Ktot) * 2u + (unsigned)(ch * 16) : OOB;
-        b_lds[i] = piece < NP ? piece * B_PLANE + row * RSB + ch * 16 : -1;
+        b_lds[i] = piece < NP ? piece * B_PLANE + row * RS + ch * 16 : -1;
     }
     const int b_dummy = 2 * STAGE + tid * 16;
     f32x4 ra[RB][4];   // [row block][k-step lo/hi 4 floats]
@@ -573,7 +580,10 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[r][j][e] = 0.f;
-    const unsigned char* b_frag = Bs + lrow * RSB + half * 16;
+    // fragment of k-step s: row lrow (+ 32 j), chunk 2 s + half — at its swizzled place in the DMA image
+    const int fsw = (lrow >> 2) & 3;
+    const int foff[2] = {DMA ? lrow * RS + ((half ^ fsw) << 4) : lrow * RS + half * 16,
+                         DMA ? lrow * RS + (((2 + half) ^ fsw) << 4) : lrow * RS + half * 16 + 32};
     auto mfma_group = [&](const bf16x8 (&a)[NP], const bf16x8 (&b)[NP], f32x16& c) {
         if (NP == 3) {
             c = Elt<F16>::mfma(a[2], b[0], c);
@@ -631,6 +641,17 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
 #pragma unroll
         for (int i = 0; i < NBL; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff_b, 0);
     };
+    // LDS-DMA of the weight tile the counters point at into the stage at byte offset `so`: round i of the 4 waves covers LDS
+    // bytes [4096 i, 4096 i + 4096); the last round is half empty for NT = 5 (whole waves: NT * 384 chunks is a multiple of 64)
+    auto dma_b = [&](int so) {
+        const int soff_b = __builtin_amdgcn_readfirstlane(min((tap * p.Cin + cc * SBK) * 2, (p.Ktot - SBK) * 2));
+#pragma unroll
+        for (int i = 0; i < NBL; ++i) {
+            if (256 * i + 64 * wave < BROWS * 4 * NP)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (void __attribute__((address_space(3)))*)(Bs + so + i * 4096 + wave * 1024), 16,
+                                                         b_voff[i], soff_b, 0, 0);
+        }
+    };
     auto store_b = [&](int i, int so) {
         if (256 * (i + 1) <= BROWS * 4 * NP)   // compile-time: this staging round is full
             *reinterpret_cast<u32x4*>(Bs + so + b_lds[i]) = rb[i];
@@ -652,28 +673,31 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
     tap_offsets(kh, kw);
 #pragma unroll
     for (int r = 0; r < RB; ++r) load_a(r);
-    load_b();
+    if (DMA) dma_b(0); else load_b();
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         split8<NP, F16>(ra[r][0], ra[r][1], af[0][r], p.ovf);
         split8<NP, F16>(ra[r][2], ra[r][3], af[1][r], p.ovf);
     }
+    if (!DMA) {
 #pragma unroll
-    for (int i = 0; i < NBL; ++i) store_b(i, 0);
+        for (int i = 0; i < NBL; ++i) store_b(i, 0);
+    }
     advance();
     tap_offsets(kh, kw);
 #pragma unroll
     for (int r = 0; r < RB; ++r) load_a(r);
-    load_b();
+    if (!DMA) load_b();
 
     for (int kt = 0; kt < KT; ++kt) {
         const int so = (kt & 1) * STAGE;
         __syncthreads();   // weight tile kt is visible; every wave is done with the other stage (tile kt-1)
+        if (DMA && kt + 1 < KT) dma_b(STAGE - so);   // the counters are at tile kt+1 here: a whole tile for the DMA to land
         bf16x8 b_cur[NP], b_nxt[NP];
-        const unsigned char* bf = b_frag + so;
+        const unsigned char* bf = Bs + so;
         u32x2 pl[NP], ph[NP];
 #pragma unroll
-        for (int q = 0; q < NP; ++q) b_nxt[q] = b_cur[q] = *reinterpret_cast<const bf16x8*>(bf + q * B_PLANE);
+        for (int q = 0; q < NP; ++q) b_nxt[q] = b_cur[q] = *reinterpret_cast<const bf16x8*>(bf + q * B_PLANE + foff[0]);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -682,16 +706,18 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
                 const int s1 = (u + 1) / NT, j1 = (u + 1) % NT;
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    b_nxt[q] = *reinterpret_cast<const bf16x8*>(bf + q * B_PLANE + j1 * 32 * RSB + s1 * 32);
+                    b_nxt[q] = *reinterpret_cast<const bf16x8*>(bf + q * B_PLANE + j1 * 32 * RS + foff[s1]);
             }
             __builtin_amdgcn_sched_barrier(0);
             if (s == 0) {   // weight tile kt+1 -> the other stage, spread over the first k-step's units
+                if (!DMA) {
 #pragma unroll
-                for (int i = 0; i < NBL; ++i)
-                    if (i * NT / NBL == j) store_b(i, STAGE - so);
+                    for (int i = 0; i < NBL; ++i)
+                        if (i * NT / NBL == j) store_b(i, STAGE - so);
+                }
                 if (j == NT - 1) {
                     advance();
-                    load_b();
+                    if (!DMA) load_b();
                 }
             } else {        // activations of tile kt+1 -> pieces, task t = (row block, 4-float slot) in unit t*NT/NTASK
                 if (j == 0) tap_offsets(kh, kw);   // of the tile advance() moved to; its loads follow once ra is free
@@ -818,6 +844,12 @@ bool conv2d_split_eligible(const ConvArgs& a) {
 template <int NP, bool F16>
 static void launch_split(const SplitP& p, int nt, hipStream_t s, int ad) {   // ad: 0 = staged, 1 / 2 = A-direct with RB row blocks
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (ad >= 1 ? p.ksplit : 1)));
+    static const bool dma = getenv("DSD_CONV_DMA") != nullptr;   // experiment: LDS-DMA weight staging in the dominant kernel
+    if (ad == 2 && dma && nt == 5 && NP == 3 && !F16) {
+        hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, true>), grid, dim3(256), 0, s, p);
+        check_launch("conv_split_ad2_dma");
+        return;
+    }
     if (ad == 2) {
         switch (nt) {
             case 1: hipLaunchKernelGGL((conv_split_ad_kernel<1, NP, F16, 2>), grid, dim3(256), 0, s, p); break;
