@@ -475,6 +475,12 @@ __device__ __forceinline__ void split8(f32x4 lo, f32x4 hi, typename Elt<F16>::v8
     }
 }
 
+// 16 B per lane from a buffer resource straight into LDS (lane-linear from the wave-uniform `lds`).  A __device__ function of
+// its own: the target builtin directly inside a __global__ template makes the HOST pass drop the instantiation silently.
+static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (void __attribute__((address_space(3)))*)lds, 16, voff, soff, 0, 0);
+}
+
 // RB = 32-row blocks per wave.  RB = 1: block tile 128 x 32*NT, two workgroups per CU.  RB = 2: block tile 256 x 32*NT,
 // ONE workgroup per CU (accumulators alone are 2*NT*16 registers): every weight fragment read from LDS feeds two MFMA
 // groups, which halves the LDS traffic per MFMA, and a k-tile carries twice the MFMAs per barrier.
@@ -648,8 +654,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
 #pragma unroll
         for (int i = 0; i < NBL; ++i) {
             if (256 * i + 64 * wave < BROWS * 4 * NP)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (void __attribute__((address_space(3)))*)(Bs + so + i * 4096 + wave * 1024), 16,
-                                                         b_voff[i], soff_b, 0, 0);
+                lds_dma16(rw, Bs + so + i * 4096 + wave * 1024, b_voff[i], soff_b);
         }
     };
     auto store_b = [&](int i, int so) {
@@ -841,11 +846,16 @@ bool conv2d_split_eligible(const ConvArgs& a) {
     return xb < 0xFFFFFF00ll && wb < 0xFFFFFF00ll;
 }
 
+// experiment: LDS-DMA weight staging in the dominant kernel (DSD_CONV_DMA=1)
+static bool conv_dma_enabled() {
+    static const bool on = getenv("DSD_CONV_DMA") != nullptr;
+    return on;
+}
+
 template <int NP, bool F16>
 static void launch_split(const SplitP& p, int nt, hipStream_t s, int ad) {   // ad: 0 = staged, 1 / 2 = A-direct with RB row blocks
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (ad >= 1 ? p.ksplit : 1)));
-    static const bool dma = getenv("DSD_CONV_DMA") != nullptr;   // experiment: LDS-DMA weight staging in the dominant kernel
-    if (ad == 2 && dma && nt == 5 && NP == 3 && !F16) {
+    if (ad == 2 && conv_dma_enabled() && nt == 5 && NP == 3 && !F16) {
         hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, true>), grid, dim3(256), 0, s, p);
         check_launch("conv_split_ad2_dma");
         return;
