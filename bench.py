@@ -308,6 +308,21 @@ class GpuLeg:
             res["roofline"], res["kernels"] = self.profile(precision, warmup + steps, profile_steps, res)
         return res
 
+    def sustained_mfma(self, achieved):
+        """The issued-bf16 rate THIS device holds on bare v_mfma_f32_32x32x16_bf16 loops with the dominant kernel's accumulator
+        tile on random operands (csrc/peak.hip), measured in this run right after the network: `peak` above is the nominal
+        2.4 GHz figure, which no MFMA-dense loop reaches because the chip lowers its clock under that load."""
+        import ctypes as C
+        from diffusion_models_dsdiff_amd import _lib
+        out = {"unit": "TFLOP/s issued bf16", "how": "dsd_bench_mfma_peak: 2048 workgroups, ~20 ms launches, mean of 5"}
+        for name, variant in (("mfma_only_registers", 0), ("mfma_plus_lds_weight_fragments", 1), ("mfma_only_zero_operands", 2)):
+            ms, tf = C.c_float(), C.c_double()
+            _lib.check(_lib.lib().dsd_bench_mfma_peak(variant, 8, 20.0, 5, C.byref(ms), C.byref(tf)))
+            out[name] = round(tf.value, 1)
+        out["frac_of_mfma_only"] = round(achieved / out["mfma_only_registers"], 4)
+        out["frac_of_mfma_plus_lds"] = round(achieved / out["mfma_plus_lds_weight_fragments"], 4)
+        return out
+
     def profile(self, precision, first_step, profile_steps, res):
         """Per-kernel durations measured live with hipEvents on the launch stream (dsd_profile_*; the captured graph is
         bypassed while profiling), and the roofline block of the dominant kernel."""
@@ -364,6 +379,8 @@ class GpuLeg:
             "whole_step_frac_issued": round(sum(v["flops"] * mfma_passes(k, precision) for k, v in rep.items())
                                             / (tot_ms / 1e3) / 1e12 / peak, 4),
             "whole_step_frac_vs_fp32_mfma_peak": round(res["whole_step_tflops"] / PEAK_FP32_MFMA_TFLOPS, 4)}
+        if ISSUED_DTYPE[precision] == "bf16":
+            roofline["sustained"] = self.sustained_mfma(alg * passes)
         kern = {}
         for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
             e = {"ms_per_step": round(v["ms"] / runs, 3), "calls_per_step": v["calls"] // runs}

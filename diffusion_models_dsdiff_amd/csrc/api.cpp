@@ -584,6 +584,69 @@ int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride,
     DSD_CATCH
 }
 
+int dsd_bench_conv2d_stamps(int N, int H, int W, int Cin, int Cout, int warm, int whatif, long long* out, int max_wgs,
+                            int* n_wgs) {
+    DSD_TRY
+    DSD_CHECK(out && n_wgs && max_wgs > 0, "bad argument");
+    hipStream_t s = nullptr;
+    const size_t nx = (size_t)N * H * W * Cin, nw = (size_t)Cout * Cin * 9, ny = (size_t)N * H * W * Cout;
+    Tmp x(nx * 4), w(nw * 4), b((size_t)Cout * 4), y(ny * 4), planes(nw * 2 * 3);
+    philox_normal(x.as<float>(), (int64_t)nx, 1, 0, s);
+    philox_normal(w.as<float>(), (int64_t)nw, 2, 0, s);
+    philox_normal(b.as<float>(), Cout, 3, 0, s);
+    ConvArgs a;
+    a.x = x.as<float>(); a.N = N; a.H = H; a.W = W; a.Cin = Cin; a.w = w.as<float>(); a.bias = b.as<float>();
+    a.Cout = Cout; a.ks = 3; a.stride = 1; a.y = y.as<float>(); a.variant = 32; a.precision = PREC_BF16X6;
+    split_weights(w.as<float>(), (int64_t)nw, 3, planes.p, s, false);
+    a.w_split = planes.p;
+    const int wgs = (int)(((int64_t)N * H * W + 255) / 256) * ((Cout + 159) / 160);
+    DSD_CHECK(wgs <= max_wgs, "room for %d workgroups needed", wgs);
+    for (int i = 0; i < warm; ++i) conv2d(a, s);
+    Tmp st((size_t)wgs * 8 * sizeof(long long));
+    DSD_HIP(hipMemsetAsync(st.p, 0, (size_t)wgs * 8 * sizeof(long long), s));
+    a.stamps = st.as<long long>();
+    a.diag = whatif;
+    for (int i = 0; i < (whatif ? 20 : 0); ++i) conv2d(a, s);   // the what-if build's own steady state
+    conv2d(a, s);
+    DSD_HIP(hipMemcpyAsync(out, st.p, (size_t)wgs * 8 * sizeof(long long), hipMemcpyDeviceToHost, s));
+    DSD_HIP(hipStreamSynchronize(s));
+    *n_wgs = wgs;
+    DSD_CATCH
+}
+
+int dsd_bench_mfma_peak(int variant, int workgroups_per_cu, float ms_target, int iters, float* avg_ms, double* tflops) {
+    DSD_TRY
+    DSD_CHECK(variant >= 0 && variant <= 3 && iters >= 1 && avg_ms && tflops, "bad argument");
+    hipStream_t s = nullptr;
+    const int wgs = 256 * (workgroups_per_cu > 0 ? std::min(workgroups_per_cu, 64) : 8);
+    Tmp src((size_t)mfma_peak_src_bytes()), sink((size_t)wgs * 256 * sizeof(float));
+    mfma_peak_fill(src.p, variant >= 2, s);
+    hipEvent_t e0, e1;
+    DSD_HIP(hipEventCreate(&e0));
+    DSD_HIP(hipEventCreate(&e1));
+    auto timed = [&](int loops, int n, double* fl) {
+        DSD_HIP(hipEventRecord(e0, s));
+        for (int i = 0; i < n; ++i) *fl = mfma_peak_launch(variant, src.p, sink.as<float>(), wgs, loops, s);
+        DSD_HIP(hipEventRecord(e1, s));
+        DSD_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        DSD_HIP(hipEventElapsedTime(&ms, e0, e1));
+        return ms / n;
+    };
+    double fl = 0.0;
+    int loops = 64;
+    const float probe = timed(loops, 1, &fl);   // also the warm-up; then size the loop for ms_target per launch
+    const float want = ms_target > 0.f ? std::min(ms_target, 200.f) : 5.f;
+    loops = (int)std::max(16.0, std::min(1.0e6, loops * (double)want / std::max(probe, 1e-3f)));
+    (void)timed(loops, 1, &fl);
+    const float ms = timed(loops, iters, &fl);
+    *avg_ms = ms;
+    *tflops = fl / (ms * 1e-3) / 1e12;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    DSD_CATCH
+}
+
 int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float* w_oihw, const float* bias, int Cout, int ks,
                        int stride, int upsample, const float* emb, const float* res, int precision, float* y, void* stream) {
     DSD_TRY

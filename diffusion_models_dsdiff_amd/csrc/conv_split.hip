@@ -60,6 +60,8 @@ struct SplitP {
     float* partial;   // [ksplit][M][Cout] raw partial sums, reduced (+ bias / embedding / residual) by splitk_reduce_kernel
     double* stats;    // GroupNorm statistics of the output, [sample][chunk][Cout][2] (GnSrc layout), or nullptr
     int stats_chunks; // chunks per sample = ohw / block-tile rows (a block tile never straddles two samples then)
+    long long* stamps;   // diagnostic instantiations only (DIAG > 0), else unused
+    int diag;            // what-if bits of the diagnostic instantiation
 };
 
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
@@ -475,6 +477,10 @@ __device__ __forceinline__ void split8(f32x4 lo, f32x4 hi, typename Elt<F16>::v8
     }
 }
 
+// (target builtins behind __device__ functions: see lds_dma16)
+static __device__ __forceinline__ long long clock_core() { return (long long)__builtin_amdgcn_s_memtime(); }
+static __device__ __forceinline__ long long clock_100mhz() { return (long long)__builtin_amdgcn_s_memrealtime(); }
+static __device__ __forceinline__ void wait_all() { __builtin_amdgcn_s_waitcnt(0); }
 // 16 B per lane from a buffer resource straight into LDS (lane-linear from the wave-uniform `lds`).  A __device__ function of
 // its own: the target builtin directly inside a __global__ template makes the HOST pass drop the instantiation silently.
 static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds, unsigned voff, int soff) {
@@ -488,8 +494,24 @@ static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, unsig
 // registers (32) and no ds_write_b128 (8 per thread and tile) in the MFMA stream.  The LDS image is then lane-linear — rows
 // of 64 B without padding — and the bank-conflict-free order is an XOR swizzle of the four 16-byte chunks of a row with
 // (row >> 2) & 3, applied on the source address and on the fragment reads (as in conv_wino.hip).
-template <int NT, int NP, bool F16, int RB, bool DMA = false>
+// DIAG > 0 = diagnostic instantiations (never on the product path): clock stamps around prologue / k-loop / epilogue, and
+// with what-if bits DIAG - 1 one cost of the loop removed (results are then garbage): 1 no activation split (raw bits),
+// 2 no activation loads, 4 no weight loads / LDS writes, 8 no barrier, 16 no weight fragment reads from LDS.
+template <int NT, int NP, bool F16, int RB, bool DMA = false, int DIAG = 0>
 __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(SplitP p) {
+    constexpr bool STAMP = DIAG > 0;
+    constexpr int WI = DIAG > 0 ? DIAG - 1 : 0;
+    // vector-memory loads issued one at a time, each right after the register it refills has been consumed, instead of in
+    // bursts of eight (stamps: 4946 -> 4763 cycles per k-tile, k-loop 246.6 -> 243.3 us; what-if bit 32 = the burst schedule)
+    constexpr bool SPREAD = RB == 2 && !DMA && !(WI & 32);
+    int soff_bs = 0, soff_as = 0;
+    auto stamp = [&](int i) {
+        if (STAMP && threadIdx.x == 0) {
+            p.stamps[(size_t)blockIdx.x * 8 + 2 * i] = clock_core();
+            p.stamps[(size_t)blockIdx.x * 8 + 2 * i + 1] = clock_100mhz();
+        }
+    };
+    stamp(0);
     typedef typename Elt<F16>::v8 bf16x8;
     constexpr int BROWS = NT * 32;
     constexpr int RS = DMA ? 64 : RSB;              // LDS row stride of a weight plane
@@ -554,6 +576,10 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
             a_voff[r][1] = ok ? base + 16u : OOB;
             a_voff[r][2] = ok ? base + 64u : OOB;
             a_voff[r][3] = ok ? base + 80u : OOB;
+            if (WI & 64) {   // (diagnostic) the same number of loads, but each one 1 KB contiguous per wave and cache-hot
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a_voff[r][q] = (unsigned)(tid * 16 + (r * 4 + q) * 4096);
+            }
         }
     };
     // ---- B staging (as in the staged kernel)
@@ -637,6 +663,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         // uniform by construction (readfirstlane keeps it scalar); clamped so that the two look-ahead tiles past the end
         // of the k-loop re-read the last channel chunk instead of the bytes behind the pixel
         const int soff_a = __builtin_amdgcn_readfirstlane(min(cc, p.cchunks - 1) * (SBK * 4));
+        if (WI & 2) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             ra[r][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[r][i], soff_a, 0));
@@ -644,6 +671,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
     auto load_b = [&]() {
         // clamped: the two look-ahead loads past the last tile re-read the last tile instead of running off the planes
         const int soff_b = __builtin_amdgcn_readfirstlane(min((tap * p.Cin + cc * SBK) * 2, (p.Ktot - SBK) * 2));
+        if (WI & 4) return;
 #pragma unroll
         for (int i = 0; i < NBL; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff_b, 0);
     };
@@ -658,6 +686,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         }
     };
     auto store_b = [&](int i, int so) {
+        if (WI & 4) return;
         if (256 * (i + 1) <= BROWS * 4 * NP)   // compile-time: this staging round is full
             *reinterpret_cast<u32x4*>(Bs + so + b_lds[i]) = rb[i];
         else
@@ -672,6 +701,18 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         }
     };
 
+    auto sp4 = [&](f32x4 v, u32x2 (&out)[NP]) {
+        if (WI & 1) {   // (diagnostic) raw bits instead of pieces: no VALU work
+            const u32x4 b = __builtin_bit_cast(u32x4, v);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) {
+                out[q].x = b[q & 3];
+                out[q].y = b[(q + 1) & 3];
+            }
+        } else {
+            split4<NP, F16>(v, out, p.ovf);
+        }
+    };
     bf16x8 af[2][RB][NP];   // A fragments of the current tile (both k-steps), in registers
     bf16x8 afn1[RB][NP];    // second k-step of the next tile (af[1] is live until the last unit)
     // prologue: tile 0 -> af / LDS stage 0, tile 1 -> ra / rb in flight
@@ -694,9 +735,10 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
     for (int r = 0; r < RB; ++r) load_a(r);
     if (!DMA) load_b();
 
+    stamp(1);
     for (int kt = 0; kt < KT; ++kt) {
         const int so = (kt & 1) * STAGE;
-        __syncthreads();   // weight tile kt is visible; every wave is done with the other stage (tile kt-1)
+        if (!(WI & 8)) __syncthreads();   // weight tile kt is visible; every wave is done with the other stage (tile kt-1)
         if (DMA && kt + 1 < KT) dma_b(STAGE - so);   // the counters are at tile kt+1 here: a whole tile for the DMA to land
         bf16x8 b_cur[NP], b_nxt[NP];
         const unsigned char* bf = Bs + so;
@@ -711,10 +753,21 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
                 const int s1 = (u + 1) / NT, j1 = (u + 1) % NT;
 #pragma unroll
                 for (int q = 0; q < NP; ++q)
-                    b_nxt[q] = *reinterpret_cast<const bf16x8*>(bf + q * B_PLANE + j1 * 32 * RS + foff[s1]);
+                    if (!(WI & 16)) b_nxt[q] = *reinterpret_cast<const bf16x8*>(bf + q * B_PLANE + j1 * 32 * RS + foff[s1]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (s == 0) {   // weight tile kt+1 -> the other stage, spread over the first k-step's units
+            if (s == 0 && SPREAD) {   // as below, but each staging register is re-loaded (tile kt+2) right after its LDS write
+                if (j == 0) {
+                    advance();
+                    soff_bs = __builtin_amdgcn_readfirstlane(min((tap * p.Cin + cc * SBK) * 2, (p.Ktot - SBK) * 2));
+                }
+#pragma unroll
+                for (int i = 0; i < NBL; ++i)
+                    if (i * NT / NBL == j) {
+                        store_b(i, STAGE - so);
+                        rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, b_voff[i], soff_bs, 0);
+                    }
+            } else if (s == 0) {   // weight tile kt+1 -> the other stage, spread over the first k-step's units
                 if (!DMA) {
 #pragma unroll
                     for (int i = 0; i < NBL; ++i)
@@ -730,16 +783,20 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
                 for (int t = 0; t < NTASK; ++t) {
                     if (t * NT / NTASK != j) continue;
                     const int r = t / 4, i = t % 4;
-                    if (i == 0) split4<NP, F16>(ra[r][0], pl, p.ovf);
+                    if (i == 0) sp4(ra[r][0], pl);
                     if (i == 1) {
-                        split4<NP, F16>(ra[r][1], ph, p.ovf);
+                        sp4(ra[r][1], ph);
                         join(pl, ph, af[0][r]);
                     }
-                    if (i == 2) split4<NP, F16>(ra[r][2], pl, p.ovf);
+                    if (i == 2) sp4(ra[r][2], pl);
                     if (i == 3) {
-                        split4<NP, F16>(ra[r][3], ph, p.ovf);
+                        sp4(ra[r][3], ph);
                         join(pl, ph, afn1[r]);
-                        load_a(r);
+                        if (!SPREAD) load_a(r);
+                    }
+                    if (SPREAD) {   // each 16-byte piece is re-loaded (tile kt+2) as soon as it has been split
+                        if (t == 0) soff_as = __builtin_amdgcn_readfirstlane(min(cc, p.cchunks - 1) * (SBK * 4));
+                        ra[r][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[r][i], soff_as, 0));
                     }
                 }
             }
@@ -754,6 +811,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
 #pragma unroll
             for (int q = 0; q < NP; ++q) af[1][r][q] = afn1[r][q];
     }
+    stamp(2);
     if (p.ksplit > 1) {   // raw partial sums; bias / embedding / residual are added once, by the reduction
         SplitP q = p;
         q.y = p.partial + (int64_t)chunk * p.M * p.Cout;
@@ -779,10 +837,14 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         for (int j = 0; j < NT; ++j) ds[j] = dq[j] = 0.0;
         st.flush(ds, dq);
         stats_reduce<NT>(p, ds, dq, Bs, m0, n0, SBM * RB, tid, wave, lrow, half);
+        if (STAMP) wait_all();   // (diagnostic) the stores have left the wave
+        stamp(3);
         return;
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) split_epilogue<NT>(p, acc[r], m0, n0, wave * RB + r, lrow, half, SBM * RB);
+    if (STAMP) wait_all();
+    stamp(3);
 }
 
 // y = sum over the k-chunks of the partial tiles (fixed order: deterministic) + bias + embedding + residual
@@ -855,6 +917,24 @@ static bool conv_dma_enabled() {
 template <int NP, bool F16>
 static void launch_split(const SplitP& p, int nt, hipStream_t s, int ad) {   // ad: 0 = staged, 1 / 2 = A-direct with RB row blocks
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (ad >= 1 ? p.ksplit : 1)));
+    if (p.stamps) {
+        if (!(ad == 2 && nt == 5 && NP == 3 && !F16 && p.ksplit == 1)) fail("conv stamps: only the dominant kernel (256-row tile, 160 columns, bf16x6) has the diagnostic build");
+        switch (p.diag) {
+            case 0: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 1>), grid, dim3(256), 0, s, p); break;
+            case 1: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 2>), grid, dim3(256), 0, s, p); break;
+            case 2: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 3>), grid, dim3(256), 0, s, p); break;
+            case 4: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 5>), grid, dim3(256), 0, s, p); break;
+            case 8: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 9>), grid, dim3(256), 0, s, p); break;
+            case 16: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 17>), grid, dim3(256), 0, s, p); break;
+            case 3: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 4>), grid, dim3(256), 0, s, p); break;
+            case 31: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 32>), grid, dim3(256), 0, s, p); break;
+            case 32: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 33>), grid, dim3(256), 0, s, p); break;
+            case 64: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 65>), grid, dim3(256), 0, s, p); break;
+            default: fail("conv stamps: what-if %d has no instantiation (0, 1, 2, 3, 4, 8, 16, 31)", p.diag);
+        }
+        check_launch("conv_split_ad2_stamped");
+        return;
+    }
     if (ad == 2 && conv_dma_enabled() && nt == 5 && NP == 3 && !F16) {
         hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, true>), grid, dim3(256), 0, s, p);
         check_launch("conv_split_ad2_dma");
@@ -994,6 +1074,8 @@ void conv2d_split(const ConvArgs& a, int nt, int ksplit, int ad, hipStream_t s) 
     }
     p.stats = nullptr;
     p.stats_chunks = 0;
+    p.stamps = a.stamps;
+    p.diag = a.diag;
     if (a.stats) {
         const int rows = ad == 2 ? 2 * SBM : SBM;
         DSD_CHECK(p.ksplit == 1 && !a.out_nchw && p.ohw % rows == 0 && p.ohw / rows == a.stats_chunks && !(ad == 1 && nt >= 4),

@@ -34,6 +34,10 @@ struct ConvArgs {
     // stats_chunks = conv2d_stats_chunks() chunks per sample; nullptr = not wanted
     double* stats = nullptr;
     int stats_chunks = 0;
+    // diagnostic build of the dominant kernel only (tools/conv_stamps.py): 8 int64 per workgroup — (s_memtime,
+    // s_memrealtime) at entry, in front of the k-loop, behind it, and after the epilogue
+    long long* stamps = nullptr;
+    int diag = 0;   // what-if bits (conv_split.hip, DIAG)
 };
 // Output size.  Default padding is ks/2 on every side (the U-Net's convolutions); pad_lo / pad_total describe the VAE's
 // Downsample (ldm/modules/diffusionmodules/model.py:78-83: F.pad (0,1,0,1) then a stride-2 conv with padding 0), i.e. no
@@ -66,6 +70,10 @@ bool conv2d_wino_shape_ok(const ConvArgs& a);      // could run there if it had 
 bool conv2d_wino_eligible(const ConvArgs& a);      // shape_ok and a.w_wino present
 bool conv2d_wino_worthwhile(const ConvArgs& a);    // shape_ok and a grid big enough to beat the direct kernel (the planner's rule)
 size_t wino_packed_bytes(int Cout, int Cin);
+// peak.hip: bare MFMA loops (diagnostic)
+int64_t mfma_peak_src_bytes();
+void mfma_peak_fill(void* src, bool zero, hipStream_t s);
+double mfma_peak_launch(int variant, const void* src, float* sink, int workgroups, int loops, hipStream_t s);
 void wino_pack_weights(const float* w_ohwi, int Cout, int Cin, void* packed, hipStream_t s);
 void conv2d_wino(const ConvArgs& a, hipStream_t s);
 int conv2d_wino_stats_chunks(const ConvArgs& a);

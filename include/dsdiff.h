@@ -293,6 +293,21 @@ int dsd_op_conv2d_prec(const float* x, int N, int H, int W, int Cin, const float
  * 50 bf16x6 as F(2,3) along the width (FLOPs reported are those of the direct form: "fp32-equivalent"). */
 int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride, int variant, int iters, float* avg_ms,
                      double* flops);
+/* Diagnostic build of the dominant kernel (bf16x6, 256-row tile, Cout = 320 -> 160-column tiles): `warm` untimed launches
+ * of the product kernel, then ONE launch of an instantiation that stamps (s_memtime, s_memrealtime) at entry, in front of
+ * the k-loop, behind it and after the epilogue.  out: 8 int64 per workgroup (host memory, room for max_wgs workgroups);
+ * *n_wgs = workgroups launched.  tools/conv_stamps.py turns this into prologue / loop / epilogue / gap times and the
+ * in-kernel clock.  whatif != 0 runs an instantiation with one cost of the k-loop removed (output garbage; timing only):
+ * 1 no activation split, 2 no activation loads, 3 both, 4 no weight loads / LDS writes, 8 no barrier, 16 no weight
+ * fragment reads, 31 all of them (the bare MFMA stream of this kernel). */
+int dsd_bench_conv2d_stamps(int N, int H, int W, int Cin, int Cout, int warm, int whatif, long long* out, int max_wgs,
+                            int* n_wgs);
+/* What the bf16 matrix pipes of this device sustain: a bare v_mfma_f32_32x32x16_bf16 loop on the dominant convolution's
+ * accumulator tile (one wave per SIMD, 160 accumulators, six products per group), `workgroups_per_cu` x 256 workgroups
+ * (<= 0: 8), about `ms_target` milliseconds per launch, average of `iters` launches (hipEvents).  variant 0: operands in
+ * registers (nothing but MFMAs: the upper bound at the clock the chip holds); 1: weight fragments re-read from LDS as the
+ * convolution does; 2 / 3: the same two on all-zero operands.  *tflops = issued bf16 MFMA TFLOP/s.  (peak.hip) */
+int dsd_bench_mfma_peak(int variant, int workgroups_per_cu, float ms_target, int iters, float* avg_ms, double* tflops);
 /* How the library would run a convolution (host-side query, no GPU work): kernel structure (0 both operands staged
  * through LDS, 1 / 2 activations read straight into registers with a 128 / 256-row tile; -1 for the fp32 kernel), N-tile
  * width in 32-column units, split-K factor and the scratch bytes the split needs.  precision as in dsd_op_conv2d_prec. */
