@@ -19,6 +19,17 @@
 // per k-tile for the whole output width, twice the LDS reads per MFMA) 210 / 368.
 // PMC (profiles/r01_pmc.json): MFMA pipe busy 71 %, clock 1.80 GHz, no LDS bank conflicts; 6 x 226 = 1.36 PF/s issued =
 // 54 % of the nominal bf16 peak, 72 % of what the matrix pipes deliver at the clock the chip holds under this load.
+// Round 2, by in-kernel clock stamps (DIAG instantiations below, tools/conv_stamps.py; 16x256x256x320->320): a workgroup
+// lives 254 us = prologue 4.3 + k-loop 245 + epilogue 4.7, successor starts 0.5 us after it; the k-loop runs 4945 cycles per
+// k-tile against 3840 of MFMA issue (78 % dense) at 1.82 GHz.  One cost removed at a time (cycles per k-tile / loop us):
+// no activation loads 4551 / 209, no weight loads + LDS writes 4506 / 227, no barrier 4604 / 238, no weight fragment reads
+// 5002 / 245, all of them 3962 / 182; the activation loads made contiguous and cache-hot 4890 / 236 (the access pattern is
+// not the cost, a vector-memory instruction is: ~50 cycles of the wave's only issue stream each).  The same tile as a BARE
+// MFMA loop (peak.hip) runs 1.87-1.92 PF/s on random operands and 2.47 on zeros on the same device: the chip is power-
+// bound, and a cycle saving comes back as clock — loads issued one at a time instead of in bursts of eight: 4946 -> 4763
+// cycles (-3.7 %), clock 1.818 -> 1.766 GHz, loop time -1.3 % (kept: SPREAD).  Weight tile by LDS-DMA instead of through
+// registers (DMA = true, DSD_CONV_DMA): no difference (228 vs 228 TF/s), the DMA piece costs the issue slots the
+// register path's load + ds_write did.
 //
 // Tiling is the fp32 kernel's (conv.hip): 256 threads, 128 x 32*NT x 32 block tile, wave = 32 rows x NT column tiles,
 // buffer loads with hardware range checks, register prefetch of the next tile, fused bias/embedding/residual epilogue.

@@ -11,9 +11,10 @@ What the reference does around ``sample_fn`` and what is rebuilt here:
     public specification; "CopyInformation" = the prediction is written with the template's header (geometry) bytes;
   * the array-level metrics of inference/test_metrics.py:21-26,149-224 (scale12bit, NRMSE, MAPE, sMAPE, logac, medsymac) and
     PSNR (:378-400, skimage's definition) as used by inference/get_metric_BraTs.py.
-Not rebuilt: the h5 slice reader (training_project/utils/my_transform.py:142-154: one ``h5py.File(path)[key][()]`` per key —
-the HDF5 container needs h5py, absent from the image; ``infer_2d.py`` takes ``.npy`` slices instead), SSIM / FID / LPIPS / ANTs
-similarity (skimage, torchmetrics, lpips, ants).
+  * the h5 slice files (preprocess/to_h5.py:40-50 writer, training_project/utils/my_transform.py:142-154 ``LoadH5`` reader): the
+    HDF5 container is read and written by ``h5lite.py`` (numpy only, pinned by files real h5py wrote) -> ``read_h5``,
+    ``write_h5``, ``LoadH5`` re-exported here.
+Not rebuilt: SSIM / FID / LPIPS / ANTs similarity (skimage, torchmetrics, lpips, ants).
 
 PARITY UNPINNED: inference/test_metrics.py and the trainers do not import here (ants, lpips, SimpleITK, Lightning), and
 the reference holds no fixtures for these functions; tests/test_host_io.py checks them against their defining formulas.
@@ -27,6 +28,8 @@ from collections import defaultdict
 from typing import Dict, Iterable, Optional, Tuple
 
 import numpy as np
+
+from .h5lite import H5File, LoadH5, read_h5, write_h5  # noqa: F401  (the h5 side of f-2)
 
 
 # ------------------------------------------------------------------------------------------------ slice bookkeeping
@@ -65,6 +68,33 @@ class VolumeAssembler:
         for si, img in slices.items():
             vol[si] = img.reshape(vol.shape[1:])      # a [1,H,W] sample broadcasts into pred_array[slice] the same way (:646)
         return vol
+
+
+def find_slice_files(root: str) -> list:
+    """Every ``<root>/<id>/<name>_<slice>.h5`` (the layout preprocess/to_h5.py:38-41 writes), ordered by (id, slice index)."""
+    found = []
+    for id_ in sorted(os.listdir(root)):
+        d = os.path.join(root, id_)
+        if not os.path.isdir(d):
+            continue
+        for fn in os.listdir(d):
+            if fn.endswith(".h5"):
+                path = os.path.join(d, fn)
+                found.append((id_, parse_slice_path(path)[1], path))
+    found.sort()
+    return [f[2] for f in found]
+
+
+def load_condition_slices(paths: Iterable[str], keys: Iterable[str]) -> np.ndarray:
+    """[N, len(keys), H, W] float32: dataset ``key`` of every slice file as one condition channel (the trainer's
+    ``torch.cat([batch[k] for k in condition_keys], 1)``, trainer_use_gaussian_diff.py:604-606).  No intensity scaling or
+    resizing is applied: the reference does those in its MONAI transform chain before the model sees the slice."""
+    keys = list(keys)
+    out = []
+    for p in paths:
+        f = H5File(p)
+        out.append(np.stack([np.asarray(f[k], dtype=np.float32) for k in keys]))
+    return np.stack(out) if out else np.zeros((0, len(keys), 0, 0), dtype=np.float32)
 
 
 # ------------------------------------------------------------------------------------------------ NIfTI-1 container

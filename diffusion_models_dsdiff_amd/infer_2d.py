@@ -2,9 +2,13 @@
 
 Reads the SAME yaml keys (model yaml: ``model.params.{unet_config, parameterization, …}``; inference yaml:
 ``sampler_setting.{sampler, sample_steps, ddim_eta, ddim_use_original_steps}``, ``test_batch_size``, ``seed``,
-``cuda_idx`` — configs/inference_config_BraTs.yaml:11-19 of the reference) but takes slices as ``.npy``
-``[N,C,H,W]`` (C = 1 or 3 condition channels, already scaled to [-1,1] and resized to a multiple of 32 as the
-reference's transforms do) and writes ``[N,1,H,W]``; NIfTI/h5/MONAI I/O is out of scope.
+``cuda_idx`` — configs/inference_config_BraTs.yaml:11-19 of the reference).  Slices come either as one ``.npy``
+``[N,C,H,W]`` (C = 1 or 3 condition channels) or as the reference's own slice files: ``--input <dir>`` with
+``<dir>/<id>/<name>_<slice>.h5`` (preprocess/to_h5.py) and ``--input-keys`` naming the datasets used as condition channels
+(h5lite.py reads them; no h5py).  Either way they are taken as already scaled to [-1,1] and sized to a multiple of 32, which
+the reference does in its MONAI transform chain (not rebuilt).  Output: ``[N,1,H,W]`` as ``.npy``, or — with an h5 input
+and ``--output <dir>`` — one ``<dir>/<id>/pred.nii.gz`` volume per id, the slices stacked at their index as
+on_predict_end does (trainer_use_gaussian_diff.py:632-655; host_io.VolumeAssembler / write_nifti).
 
 Sampler selection follows TryTrainerDiffusion.on_predict_start (trainers/trainer_use_gaussian_diff.py:586-600):
 the diffusion is rebuilt with ``timestep_respacing = str(sample_steps)`` and ``rescale_timesteps = True`` when
@@ -31,7 +35,8 @@ def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__.split("\n")[0])
     ap.add_argument("--model-yaml", required=True)
     ap.add_argument("--infer-yaml", required=True)
-    ap.add_argument("--input", required=True, help=".npy [N,C,H,W] condition slices")
+    ap.add_argument("--input", required=True, help=".npy [N,C,H,W] condition slices, or a directory <id>/<name>_<slice>.h5")
+    ap.add_argument("--input-keys", default="F_Data1", help="h5 input: comma-separated dataset names = condition channels")
     ap.add_argument("--output", required=True)
     ap.add_argument("--ckpt", default=None, help="torch state_dict file (plain tensors; keys may carry model.diffusion_model.)")
     ap.add_argument("--synthetic-weights", type=int, default=None, help="seed: random-init weights (no checkpoint)")
@@ -98,7 +103,15 @@ def main(argv=None):
     sample_fn = {"ddim": diffusion.ddim_sample_loop, "dpm": diffusion.dpm_solver_sample_loop}.get(which, diffusion.p_sample_loop)
     extra = {"eta": float(ss.get("ddim_eta", 0))} if which == "ddim" else {}
 
-    cond_all = np.load(args.input, mmap_mode="r")
+    h5_paths = None
+    if os.path.isdir(args.input):
+        from . import host_io
+        h5_paths = host_io.find_slice_files(args.input)
+        if not h5_paths:
+            raise SystemExit(f"no <id>/<name>_<slice>.h5 files under {args.input}")
+        cond_all = host_io.load_condition_slices(h5_paths, args.input_keys.split(","))
+    else:
+        cond_all = np.load(args.input, mmap_mode="r")
     xT_all = np.load(args.x_T, mmap_mode="r") if args.x_T else None
     n = cond_all.shape[0]
     mine = parallel.shard_indices(n, rank, ws)
@@ -119,7 +132,16 @@ def main(argv=None):
     unet.set_slice_ids(None)
     local_out = torch.cat(outs) if outs else torch.zeros((0, 1) + tuple(cond_all.shape[2:]), device=dev)
     full = parallel.gather_slices(local_out, n, 0)
-    if rank == 0:
+    if rank == 0 and h5_paths is not None and not args.output.endswith(".npy"):
+        from . import host_io
+        asm = host_io.VolumeAssembler()
+        asm.add_paths(h5_paths, full.cpu().numpy())
+        for id_ in asm.ids():
+            os.makedirs(os.path.join(args.output, id_), exist_ok=True)
+            vol = asm.volume(id_)
+            host_io.write_nifti(os.path.join(args.output, id_, "pred.nii.gz"), vol)
+            print(f"wrote {os.path.join(args.output, id_, 'pred.nii.gz')}: {tuple(vol.shape)}")
+    elif rank == 0:
         np.save(args.output, full.cpu().numpy())
         print(f"wrote {args.output}: {tuple(full.shape)}")
     if ws > 1:

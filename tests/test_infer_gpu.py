@@ -49,3 +49,45 @@ def test_infer_2d_ddim_end_to_end(tmp_path):
     od = OS.DiffusionA(steps=1000, timestep_respacing="10", rescale_timesteps=True, parameterization="v")
     yo = od.ddim_sample_loop(lambda xx, tt: O.unet_forward(cfg, sd, xx, tt)[0], xT, torch.zeros((10, n, 1, 32, 32)), [cond])
     assert rel_l2(out, yo) < 1e-4
+
+
+def test_infer_2d_h5_slices_to_nifti_volumes(tmp_path):
+    """The reference's own file formats either side of the path (SURVEY f-2): <id>/layer_<z>.h5 slice files in
+    (preprocess/to_h5.py layout, read by h5lite), one NIfTI volume per id out, slices at their index; the volumes equal what
+    the .npy route gives for the same slices (x_T is keyed by the global slice number in both)."""
+    from diffusion_models_dsdiff_amd import host_io
+    gm = golden("model")
+    params = json.loads(str(gm["tiny_cfg"]))
+    sd = fixture_params(gm, "tiny")
+    model_yaml = {"model": {"params": {"parameterization": "v", "diffusion_steps": 1000, "noise_schedule": "linear",
+                                       "unet_config": {"target": "UNet_DS_Diff.model.DSUnetModel", "params": params}}}}
+    infer_yaml = {"cuda_idx": 0, "test_batch_size": 4, "seed": 7,
+                  "sampler_setting": {"sampler": "ddim", "sample_steps": 4, "ddim_eta": 0}}
+    (tmp_path / "m.yaml").write_text(yaml.safe_dump(model_yaml))
+    (tmp_path / "i.yaml").write_text(yaml.safe_dump(infer_yaml))
+    torch.save(sd, tmp_path / "ckpt.pt")
+    depth = {"vol_a": 3, "vol_b": 2}
+    cond = cond_image((5, 1, 32, 32), 99).numpy()
+    k = 0
+    for id_, d in depth.items():
+        os.makedirs(tmp_path / "h5" / id_)
+        for z in range(d):
+            host_io.write_h5(str(tmp_path / "h5" / id_ / f"layer_{z}.h5"), {"F_Data1": cond[k, 0], "S_Data1": np.zeros((32, 32), np.float32)})
+            k += 1
+    np.save(tmp_path / "in.npy", cond)
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    base = [sys.executable, "-m", "diffusion_models_dsdiff_amd.infer_2d", "--model-yaml", str(tmp_path / "m.yaml"),
+            "--infer-yaml", str(tmp_path / "i.yaml"), "--ckpt", str(tmp_path / "ckpt.pt")]
+    r = subprocess.run(base + ["--input", str(tmp_path / "h5"), "--input-keys", "F_Data1", "--output", str(tmp_path / "pred")],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    r = subprocess.run(base + ["--input", str(tmp_path / "in.npy"), "--output", str(tmp_path / "out.npy")],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    flat = np.load(tmp_path / "out.npy")
+    k = 0
+    for id_, d in depth.items():
+        vol, _hdr = host_io.read_nifti(str(tmp_path / "pred" / id_ / "pred.nii.gz"))
+        assert vol.shape == (d, 32, 32)
+        assert np.array_equal(vol, flat[k:k + d, 0])
+        k += d
