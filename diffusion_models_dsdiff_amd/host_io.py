@@ -14,10 +14,14 @@ What the reference does around ``sample_fn`` and what is rebuilt here:
   * the h5 slice files (preprocess/to_h5.py:40-50 writer, training_project/utils/my_transform.py:142-154 ``LoadH5`` reader): the
     HDF5 container is read and written by ``h5lite.py`` (numpy only, pinned by files real h5py wrote) -> ``read_h5``,
     ``write_h5``, ``LoadH5`` re-exported here.
-Not rebuilt: SSIM / FID / LPIPS / ANTs similarity (skimage, torchmetrics, lpips, ants).
+  * the two scikit-image metrics behind ``psnr`` / ``ssim`` (test_metrics.py:7-8,227-246,378-400): ``peak_signal_noise_ratio``,
+    ``structural_similarity`` restated from scikit-image 0.18 and PINNED by values real scikit-image computed
+    (tests/golden/metrics.npz, generator tests/golden/gen_metrics.py).
+Not rebuilt: multi-scale SSIM (torchmetrics), CW-SSIM (pyssim), FID / LPIPS (network weights), ANTs similarity, mutual information.
 
-PARITY UNPINNED: inference/test_metrics.py and the trainers do not import here (ants, lpips, SimpleITK, Lightning), and
-the reference holds no fixtures for these functions; tests/test_host_io.py checks them against their defining formulas.
+PARITY UNPINNED for the array metrics and the slice bookkeeping: inference/test_metrics.py and the trainers do not import
+here (ants, lpips, SimpleITK, Lightning), and the reference holds no fixtures for these functions; tests/test_host_io.py checks
+them against their defining formulas.  The HDF5 container and the scikit-image metrics ARE pinned (above).
 """
 from __future__ import annotations
 
@@ -207,6 +211,50 @@ def medsymac(true_array, pred_array, mask=None):
     return float(np.exp(np.median(np.fabs(np.log(p / t)))) - 1)
 
 
+def peak_signal_noise_ratio(image_true, image_test, data_range):
+    """scikit-image's metric (skimage.metrics.peak_signal_noise_ratio, 0.18): both images as float64, 10 log10(R^2 / MSE)."""
+    t, p = np.asarray(image_true, dtype=np.float64), np.asarray(image_test, dtype=np.float64)
+    return float(10.0 * np.log10(float(data_range) ** 2 / np.mean((t - p) ** 2)))
+
+
+def structural_similarity(im1, im2, win_size=7, data_range=None, K1=0.01, K2=0.03):
+    """scikit-image's mean SSIM (skimage.metrics.structural_similarity, 0.18 defaults: uniform window over every axis,
+    sample covariance, float64): local means / (co)variances by a ``win_size``^ndim box filter (borders reflected), the SSIM
+    map  (2 ux uy + C1)(2 vxy + C2) / ((ux^2 + uy^2 + C1)(vx + vy + C2)),  C = (K R)^2, averaged over the interior (the
+    (win_size - 1) / 2 border is cropped)."""
+    from scipy.ndimage import uniform_filter
+    x, y = np.asarray(im1, dtype=np.float64), np.asarray(im2, dtype=np.float64)
+    if x.shape != y.shape:
+        raise ValueError("Input images must have the same dimensions.")
+    if win_size % 2 != 1 or min(x.shape) < win_size:
+        raise ValueError("win_size must be odd and not exceed any image side")
+    if data_range is None:
+        raise ValueError("data_range must be given for floating-point images")
+    npix = win_size ** x.ndim
+    cov_norm = npix / (npix - 1.0)
+    ux, uy = uniform_filter(x, size=win_size), uniform_filter(y, size=win_size)
+    uxx, uyy, uxy = uniform_filter(x * x, size=win_size), uniform_filter(y * y, size=win_size), uniform_filter(x * y, size=win_size)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    R = float(data_range)
+    C1, C2 = (K1 * R) ** 2, (K2 * R) ** 2
+    S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2))
+    pad = (win_size - 1) // 2
+    return float(S[tuple(slice(pad, n - pad) for n in S.shape)].mean(dtype=np.float64))
+
+
+def ssim(true_array, pred_array, mask=None):
+    """:227-246 — crop to the mask's bounding box, 12-bit rescale, scikit-image's SSIM with a 9^3 window and the cropped
+    reference's range.  (The reference's version only defines the cropped images when a mask is given; without one the whole
+    volume is used here.)"""
+    t, p = np.asarray(true_array), np.asarray(pred_array)
+    if mask is not None:
+        nz = np.nonzero(mask.astype(bool))
+        sl = tuple(slice(int(a.min()), int(a.max())) for a in nz)
+        t, p = t[sl], p[sl]
+    t, p = scale12bit(t), scale12bit(p)
+    return structural_similarity(t, p, win_size=9, data_range=t.max() - t.min())
+
+
 def psnr(true_array, pred_array, mask=None):
     """:378-400 — crop to the mask's bounding box (exclusive upper bound, as the reference slices), zero outside the mask,
     then 10 log10(data_range^2 / MSE) with data_range = max - min of the cropped reference (skimage's definition)."""
@@ -214,6 +262,5 @@ def psnr(true_array, pred_array, mask=None):
     t, p = np.where(m, true_array, 0), np.where(m, pred_array, 0)
     nz = np.nonzero(m)
     sl = tuple(slice(int(a.min()), int(a.max())) for a in nz)
-    t, p = t[sl].astype(np.float64), p[sl].astype(np.float64)
-    rng = t.max() - t.min()
-    return float(10.0 * np.log10(rng * rng / np.mean((t - p) ** 2)))
+    t, p = t[sl], p[sl]
+    return peak_signal_noise_ratio(t, p, data_range=t.max() - t.min())

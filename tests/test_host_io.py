@@ -80,3 +80,24 @@ def test_metrics_against_their_definitions():
     assert np.isclose(H.psnr(t.copy(), p.copy(), m), want)
     z = np.full((4, 4, 4), 3.0)
     assert np.allclose(H.scale12bit(np.array([1.0, 2.0, 3.0])), [2048 - 400 * np.sqrt(1.5), 2048.0, 2048 + 400 * np.sqrt(1.5)])
+
+
+def test_skimage_metrics_against_real_skimage():
+    """peak_signal_noise_ratio / structural_similarity vs values scikit-image 0.18.3 itself computed (tests/golden/metrics.npz)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics.npz"))
+    for name in ("v3", "s2"):
+        t, p = g[name + "_true"], g[name + "_pred"]
+        dr = t.max() - t.min()
+        assert abs(H.peak_signal_noise_ratio(t, p, data_range=dr) - float(g[name + "_psnr"])) < 1e-9
+        assert abs(H.structural_similarity(t, p, win_size=9, data_range=dr) - float(g[name + "_ssim9"])) < 1e-9
+        assert abs(H.structural_similarity(t, p, data_range=dr) - float(g[name + "_ssim7"])) < 1e-9
+    # the reference's wrappers on top: mask crop (exclusive upper bound) + 12-bit rescale for ssim, zeroing + crop for psnr
+    t, p = g["v3_true"].copy(), g["v3_pred"].copy()
+    mask = np.zeros(t.shape, dtype=np.uint8)
+    mask[1:13, 4:37, 3:33] = 1
+    sl = (slice(1, 12), slice(4, 36), slice(3, 32))
+    tt, pp = H.scale12bit(t[sl]), H.scale12bit(p[sl])
+    assert H.ssim(t, p, mask) == H.structural_similarity(tt, pp, win_size=9, data_range=tt.max() - tt.min())
+    assert 0.5 < H.ssim(t, p, mask) < 1.0
+    assert H.psnr(t, p, mask) == H.peak_signal_noise_ratio(t[sl], p[sl], data_range=t[sl].max() - t[sl].min())
