@@ -10,9 +10,9 @@ _lib.require_gpu(0)
 shape = [int(v) for v in sys.argv[1:6]] or [16, 256, 256, 320, 320]
 whatifs = [int(v) for v in os.environ.get("DSD_WHATIF", "0").split(",")]
 cap = 1 << 16
-WHAT = {0: "product kernel", 1: "no activation split", 2: "no activation loads", 3: "no activation loads / split", 4: "no weight loads / LDS writes",
+WHAT = {0: "product kernel", 2: "no activation loads", 4: "no weight loads / LDS writes",
         8: "no barrier", 16: "no weight fragment reads", 31: "bare MFMA stream of this kernel",
-        32: "loads issued in bursts of eight (the schedule before r2; correct results)", 64: "activation loads coalesced + cache-hot (same count)"}
+        32: "loads issued in bursts of eight (the schedule before r2; correct results)"}
 for wi in whatifs:
   buf = np.zeros((cap, 8), dtype=np.int64)
   n = C.c_int()
