@@ -304,3 +304,34 @@ def test_philox_normal_moments(ops):
     z2 = ops.philox_normal(1 << 20, 1234, 8).cpu().double()
     assert abs((z * z2).mean()) < 5e-3                       # different steps are uncorrelated
     assert torch.equal(ops.philox_normal(4096, 99, 3), ops.philox_normal(4096, 99, 3))   # deterministic
+
+
+def test_diagnostic_entry_points():
+    """The measurement helpers behind bench.py's roofline.sustained and tools/conv_stamps.py: bare-MFMA loop rates are
+    physical (below the 2.5 PF nominal peak, zeros faster than random data), and the stamped instantiation of the dominant
+    convolution reports ordered clock stamps for every workgroup."""
+    import ctypes as C
+    from diffusion_models_dsdiff_amd import _lib
+    L = _lib.lib()
+    rates = {}
+    for v in (0, 1, 2):
+        ms, tf = C.c_float(), C.c_double()
+        _lib.check(L.dsd_bench_mfma_peak(v, 4, 2.0, 3, C.byref(ms), C.byref(tf)))
+        rates[v] = tf.value
+        assert ms.value > 0 and 300.0 < tf.value < 2600.0, (v, ms.value, tf.value)
+    assert rates[2] > rates[0] > 0.9 * rates[1]      # zeros hold a higher clock; LDS-fed is not faster than register-fed
+    ms, tf = C.c_float(), C.c_double()
+    assert L.dsd_bench_mfma_peak(7, 4, 2.0, 3, C.byref(ms), C.byref(tf)) != 0
+    import numpy as np
+    buf = np.zeros((512, 8), dtype=np.int64)
+    n = C.c_int()
+    _lib.check(L.dsd_bench_conv2d_stamps(1, 256, 256, 320, 320, 2, 0, buf.ctypes.data_as(C.POINTER(C.c_longlong)), 512, C.byref(n)))
+    assert n.value == 512                             # 65536 output pixels / 256 rows x 2 column tiles of 160
+    st = buf[: n.value]
+    assert (st > 0).all()
+    for c in (0, 1):                                  # core clock and 100 MHz clock: entry <= loop start < loop end <= exit
+        t = st[:, c::2]
+        assert (t[:, 0] <= t[:, 1]).all() and (t[:, 1] < t[:, 2]).all() and (t[:, 2] <= t[:, 3]).all()
+    assert L.dsd_bench_conv2d_stamps(1, 256, 256, 320, 320, 0, 5, buf.ctypes.data_as(C.POINTER(C.c_longlong)), 512, C.byref(n)) != 0   # not instantiated
+    assert L.dsd_bench_conv2d_stamps(1, 256, 256, 320, 320, 0, 0, buf.ctypes.data_as(C.POINTER(C.c_longlong)), 8, C.byref(n)) != 0     # too little room
+    assert L.dsd_bench_conv2d_stamps(1, 64, 64, 320, 320, 0, 0, buf.ctypes.data_as(C.POINTER(C.c_longlong)), 512, C.byref(n)) != 0     # split-K shape: no diagnostic build
