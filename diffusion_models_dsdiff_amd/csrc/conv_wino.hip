@@ -92,6 +92,12 @@ __device__ __forceinline__ void split8x3(f32x4 lo, f32x4 hi, bf16x8 (&out)[3]) {
     }
 }
 
+// Measured and removed (round 2): giving the narrow last N tile of TWO neighbouring M tiles to one block, so that every
+// block carries the same MFMA work and the blocks sharing activations stay in step: 228.9 / 240.1 TF/s against 232.1 / 247.4
+// unpaired on 16x256x256x{320,640}->320 — the faster 640-channel layers (267-277) are not faster because their N tiles are
+// equal.  What separates this kernel from its MFMA skeleton is vector-memory ISSUE: per k-tile and wave 4 activation + 12
+// weight LDS-DMA instructions at ~60 cycles each beside 96 MFMAs (3072 cycles), twice the direct kernel's ratio.
+//
 // NT = column tiles (of 32 output channels) this block really has: 4, or 2 in the last N tile of a layer whose Cout is
 // 64 (mod 128).  A compile-time count: a run-time `if (j < ntv)` around the MFMAs makes every accumulator a phi of
 // "multiplied / not multiplied", which doubles the AGPR demand and spills the whole accumulator file.
