@@ -10,9 +10,10 @@ Specification Version 3.0"):
                                  heap + SNOD: what ``h5py.File(..., 'w')`` writes by default) and as compact link messages
                                  (``libver='latest'``, up to 8 links); object headers v1 and v2 with continuation blocks;
                                  datasets contiguous, compact or chunked through a v1 B-tree (``compression='gzip'``,
-                                 ``shuffle``, ``fletcher32``), layout message v1-v3 and v4 (contiguous / compact / single chunk);
+                                 ``shuffle``, ``fletcher32``), layout message v1-v3 and v4 (contiguous / compact / single chunk / implicit /
+                                 fixed-array chunk index);
                                  fixed-point and IEEE floating-point types of 1-8 bytes, either byte order.
-                                 Anything else (dense link storage, v2 B-tree chunk indices, compound / string / variable-
+                                 Anything else (dense link storage, extensible-array / v2 B-tree chunk indices, compound / string / variable-
                                  length types, external or virtual storage) raises NotImplementedError naming the feature.
   write_h5(path, arrays)         the file ``to_h5.py`` produces: superblock v0, one root symbol table, contiguous datasets.
   LoadH5(path_key, keys)         the reference's dictionary transform, same arguments and effect.
@@ -228,7 +229,17 @@ class _Dataset:
                 for k, idx in enumerate(np.ndindex(*grid)):
                     self._place(out, f._read(addr + k * csize, csize), tuple(i * c for i, c in zip(idx, cdims)), cdims)
             return out
-        _unsupported({3: "fixed-array", 4: "extensible-array", 5: "v2 B-tree"}.get(index, f"type {index}") + " chunk index")
+        if index == 3:   # fixed array: one entry per chunk of the grid, row-major
+            addr = f._addr(b, off + 1)   # (one byte of page bits in front of the header address)
+            grid = [-(-s // c) for s, c in zip(self.shape, cdims)]
+            if addr != UNDEF:
+                for idx, (caddr, size, mask) in zip(np.ndindex(*grid), f._fixed_array(addr, int(np.prod(grid)))):
+                    if caddr == UNDEF:
+                        continue
+                    raw = f._read(caddr, size if size else int(np.prod(cdims)) * self.dtype.itemsize)
+                    self._place(out, self._unfilter(raw, mask) if size else raw, tuple(i * c for i, c in zip(idx, cdims)), cdims)
+            return out
+        _unsupported({4: "extensible-array", 5: "v2 B-tree"}.get(index, f"type {index}") + " chunk index")
 
 
 class H5File:
@@ -428,6 +439,47 @@ class H5File:
                 yield size, mask, offs, child
             else:
                 yield from self._chunk_btree(child, ndims)
+
+    def _fixed_array(self, addr: int, nchunks: int):
+        """(chunk address, stored size or 0 when unfiltered, filter mask) per chunk — "FAHD" header + "FADB" data block."""
+        h = self._read(addr, 8 + self.L + self.O)
+        if h[:4] != b"FAHD":
+            raise H5FormatError("fixed-array header signature")
+        client, esize, page_bits = h[5], h[6], h[7]
+        nelm = int.from_bytes(h[8: 8 + self.L], "little")
+        dblk = self._addr(h, 8 + self.L)
+        if nelm < nchunks:
+            raise H5FormatError("fixed array holds fewer entries than the chunk grid")
+        if dblk == UNDEF:
+            return [(UNDEF, 0, 0)] * nchunks
+        if self._read(dblk, 4) != b"FADB":
+            raise H5FormatError("fixed-array data block signature")
+        p = dblk + 6 + self.O
+        page = 1 << page_bits
+        def entries(at: int, n: int):
+            raw = self._read(at, n * esize)
+            for i in range(n):
+                e = raw[i * esize: (i + 1) * esize]
+                a = self._addr(e, 0)
+                if client == 0:
+                    yield a, 0, 0
+                else:
+                    w = esize - self.O - 4
+                    yield a, int.from_bytes(e[self.O: self.O + w], "little"), struct.unpack_from("<I", e, self.O + w)[0]
+        if nelm <= page:
+            return list(entries(p, nchunks))
+        npages = -(-nelm // page)
+        bitmap = self._read(p, (npages + 7) // 8)
+        p += (npages + 7) // 8 + 4          # the data block's own checksum follows the bitmap; pages follow it
+        out = []
+        for pg in range(npages):
+            n = min(page, nelm - pg * page)
+            if bitmap[pg // 8] >> (7 - pg % 8) & 1:
+                out.extend(entries(p, n))
+            else:
+                out.extend([(UNDEF, 0, 0)] * n)   # page never written
+            p += n * esize + 4
+        return out[:nchunks]
 
     # ---- mapping interface
     def keys(self) -> List[str]:

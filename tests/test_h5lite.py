@@ -128,3 +128,80 @@ def test_slice_directory_to_condition_batch(tmp_path):
     asm = host_io.VolumeAssembler()
     asm.add_paths(paths, cond[:, :1])
     assert np.array_equal(asm.volume("case_a"), vols["case_a"][:, 1])   # slice 10 lands behind slice 9, not behind slice 1
+
+
+@pytest.mark.skipif(not os.path.exists(PY39), reason="no interpreter with h5py in this image")
+def test_reader_against_h5py_variants(tmp_path):
+    """Files written on the spot by real h5py with the options a slice file can meet: scalar and 1-D..4-D datasets, many
+    datasets in one group (several symbol nodes / a deeper B-tree), chunk shapes that do not divide the dataset, gzip levels,
+    shuffle, fletcher32, every integer / float width, both byte orders, old and new library bounds (v1 B-tree and
+    fixed-array chunk indices, paged and not), nested groups."""
+    code = r'''
+import sys, h5py, numpy as np
+out = sys.argv[1]
+rng = np.random.default_rng(123)
+exp = {}
+def arr(shape, dt):
+    dt = np.dtype(dt)
+    if dt.kind == "f":
+        return rng.standard_normal(shape).astype(dt)
+    info = np.iinfo(dt.newbyteorder("="))
+    return rng.integers(max(info.min, -1000), min(info.max, 1000), shape).astype(dt)
+for tag, kw in (("old", {}), ("v110", {"libver": ("v110", "v110")}), ("new", {"libver": "latest"})):
+    with h5py.File(f"{out}/{tag}.h5", "w", **kw) as f:
+        items = {}
+        for i, dt in enumerate(["<f4", "<f8", "<f2", ">f4", ">f8", "<i1", "<i2", "<i4", "<i8", "<u1", "<u2", "<u4", "<u8", ">i2", ">u4"]):
+            items[f"d{i:02d}"] = arr((5, 7), dt)
+        items["scalar"] = np.float32(3.25)
+        items["vec"] = arr((11,), "<f4")
+        items["vol"] = arr((3, 9, 10), "<i2")
+        items["four"] = arr((2, 3, 4, 5), "<f8")
+        if tag == "old":                      # >8 links in a new-style group = dense storage (outside the subset)
+            for k, v in items.items():
+                f[k] = v
+                exp[f"{tag}/{k}"] = np.asarray(v)
+            for j in range(40):
+                f[f"many_{j:02d}"] = np.full((2, 2), j, dtype=np.int32)
+                exp[f"{tag}/many_{j:02d}"] = np.full((2, 2), j, dtype=np.int32)
+        else:
+            for k in ("d00", "d03", "d06", "scalar", "vol"):
+                f[k] = items[k]
+                exp[f"{tag}/{k}"] = np.asarray(items[k])
+        g = f.create_group("grp")
+        a = arr((37, 29), "<f4")
+        g.create_dataset("ragged_chunks", data=a, chunks=(16, 10), compression="gzip", compression_opts=1)
+        exp[f"{tag}/grp/ragged_chunks"] = a
+        b = arr((64, 48), "<i2")
+        g.create_dataset("shuffled", data=b, chunks=(64, 48), compression="gzip", shuffle=True, fletcher32=True)
+        exp[f"{tag}/grp/shuffled"] = b
+        c = arr((9, 9), ">f8")
+        g.create_dataset("chunk_plain", data=c, chunks=(4, 4))
+        exp[f"{tag}/grp/chunk_plain"] = c
+        e = arr((70, 66), "<i4")
+        g.create_dataset("many_chunks", data=e, chunks=(2, 2))              # 1155 chunks: a paged fixed array under v1.10+
+        exp[f"{tag}/grp/many_chunks"] = e
+        h = arr((70, 66), "<f4")
+        g.create_dataset("many_gz", data=h, chunks=(2, 3), compression="gzip")
+        exp[f"{tag}/grp/many_gz"] = h
+        d = arr((6,), "<u1")
+        g.create_dataset("unwritten", shape=(4, 4), dtype="<f4")            # never written: zeros
+        exp[f"{tag}/grp/unwritten"] = np.zeros((4, 4), np.float32)
+        g.create_group("sub")["deep"] = d
+        exp[f"{tag}/grp/sub/deep"] = d
+np.savez(f"{out}/exp.npz", **{k: v.astype(v.dtype.newbyteorder("=")) for k, v in exp.items()})
+print("ok")
+'''
+    env = {k: v for k, v in os.environ.items() if not k.startswith("PYTHON")}
+    r = subprocess.run([PY39, "-c", code, str(tmp_path)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-3000:]
+    exp = np.load(str(tmp_path / "exp.npz"))
+    files = {}
+    n = 0
+    for key in exp.files:
+        tag, name = key.split("/", 1)
+        f = files.setdefault(tag, h5lite.H5File(str(tmp_path / f"{tag}.h5")))
+        got = f[name]
+        want = exp[key]
+        assert got.shape == want.shape and got.dtype == want.dtype and np.array_equal(got, want), key
+        n += 1
+    assert n >= 90
