@@ -228,7 +228,7 @@ class DSUnetModel(NativeModule):
             raise NotImplementedError("use_spatial_transformer=True raises NameError in the reference too "
                                       "(UNet_DS_Diff/model.py:20 imports only SpatialTransformer_fft)")
         if context_dim is not None:
-            assert use_spatial_transformer, "Fool!! You forgot to use the spatial transformer for your cross-attention conditioning..."
+            assert use_spatial_transformer, "context_dim is only meaningful with use_spatial_transformer=True"
         if num_heads == -1:
             assert num_head_channels != -1, "Either num_heads or num_head_channels has to be set"
         if num_head_channels == -1:

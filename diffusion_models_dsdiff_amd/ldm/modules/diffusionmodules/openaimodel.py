@@ -25,11 +25,11 @@ class UNetModel(_Block):
                  disable_middle_self_attn=False, use_linear_in_transformer=False, adm_in_channels=None, device_index=0):
         super().__init__()
         if use_spatial_transformer:
-            assert context_dim is not None, 'Fool!! You forgot to include the dimension of your cross-attention conditioning...'
+            assert context_dim is not None, 'use_spatial_transformer=True needs context_dim (the width of the cross-attention conditioning)'
             raise NotImplementedError("the latent path's yaml sets use_spatial_transformer: False; the transformer blocks exist as "
                                       "block handles (blocks.SpatialTransformer) but not inside this model")
         if context_dim is not None:
-            assert use_spatial_transformer, 'Fool!! You forgot to use the spatial transformer for your cross-attention conditioning...'
+            assert use_spatial_transformer, 'context_dim is only meaningful with use_spatial_transformer=True'
         if num_heads == -1:
             assert num_head_channels != -1, 'Either num_heads or num_head_channels has to be set'
         if num_head_channels == -1:
