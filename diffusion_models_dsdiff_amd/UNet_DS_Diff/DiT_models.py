@@ -90,42 +90,48 @@ class DiT(_Block):
         return out
 
     def forward_with_cfg(self, x, t, y, cfg_scale):
-        """:245-262 (classifier-free guidance on the first three channels, as the reference)."""
-        half = x[: len(x) // 2]
-        combined = torch.cat([half, half], dim=0)
-        model_out = self.forward(combined, t, y)
-        eps, rest = model_out[:, :3], model_out[:, 3:]
-        cond_eps, uncond_eps = torch.split(eps, len(eps) // 2, dim=0)
-        half_eps = uncond_eps + cfg_scale * (cond_eps - uncond_eps)
-        eps = torch.cat([half_eps, half_eps], dim=0)
-        return torch.cat([eps, rest], dim=1)
+        """:245-262 — classifier-free guidance: the batch holds the same samples twice (conditional half first, then the
+        null-label half); only its first half is used as input, the guided noise estimate e_u + s (e_c - e_u) is formed on the
+        first three output channels and written to both halves, the remaining channels pass through."""
+        n = x.shape[0] // 2
+        out = self.forward(torch.cat([x[:n], x[:n]]), t, y)
+        e_c, e_u = out[:n, :3], out[n:, :3]
+        guided = e_u + cfg_scale * (e_c - e_u)
+        return torch.cat([guided.repeat(2, 1, 1, 1), out[:, 3:]], dim=1)
 
 
-# ---- fixed sin-cos position table (:269-312; numpy, float64 like the reference)
-def get_2d_sincos_pos_embed(embed_dim, grid_size, cls_token=False, extra_tokens=0):
-    grid_h = np.arange(grid_size, dtype=np.float32)
-    grid_w = np.arange(grid_size, dtype=np.float32)
-    grid = np.stack(np.meshgrid(grid_w, grid_h), axis=0).reshape([2, 1, grid_size, grid_size])   # w goes first
-    pos_embed = get_2d_sincos_pos_embed_from_grid(embed_dim, grid)
-    if cls_token and extra_tokens > 0:
-        pos_embed = np.concatenate([np.zeros([extra_tokens, embed_dim]), pos_embed], axis=0)
-    return pos_embed
-
-
-def get_2d_sincos_pos_embed_from_grid(embed_dim, grid):
-    assert embed_dim % 2 == 0
-    emb_h = get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[0])
-    emb_w = get_1d_sincos_pos_embed_from_grid(embed_dim // 2, grid[1])
-    return np.concatenate([emb_h, emb_w], axis=1)
+# ---- fixed sin-cos position table (:269-312): float64 numpy, the same operations in the same order as the reference so
+# that a default-initialised model carries the same buffer
+def _sincos_1d(dim, positions):
+    """[len(positions), dim]: sin | cos of position x 10000^(-i / (dim / 2)), i = 0 .. dim / 2 - 1."""
+    if dim % 2:
+        raise ValueError("the embedding width must be even")
+    freq = np.arange(dim // 2, dtype=np.float64)
+    freq /= dim / 2.
+    freq = 1. / 10000 ** freq
+    angle = np.einsum('m,d->md', np.asarray(positions).reshape(-1), freq)
+    return np.concatenate([np.sin(angle), np.cos(angle)], axis=1)
 
 
 def get_1d_sincos_pos_embed_from_grid(embed_dim, pos):
-    assert embed_dim % 2 == 0
-    omega = np.arange(embed_dim // 2, dtype=np.float64)
-    omega /= embed_dim / 2.
-    omega = 1. / 10000 ** omega
-    out = np.einsum('m,d->md', pos.reshape(-1), omega)
-    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+    return _sincos_1d(embed_dim, pos)
+
+
+def get_2d_sincos_pos_embed_from_grid(embed_dim, grid):
+    """grid[0] / grid[1]: the two coordinate planes; each gets half of the width."""
+    if embed_dim % 2:
+        raise ValueError("the embedding width must be even")
+    return np.concatenate([_sincos_1d(embed_dim // 2, grid[0]), _sincos_1d(embed_dim // 2, grid[1])], axis=1)
+
+
+def get_2d_sincos_pos_embed(embed_dim, grid_size, cls_token=False, extra_tokens=0):
+    """[grid_size^2 (+ extra_tokens zero rows in front), embed_dim]; the column coordinate fills the first half."""
+    axis = np.arange(grid_size, dtype=np.float32)
+    cols, rows = np.meshgrid(axis, axis)                       # meshgrid(w, h): plane 0 varies along the width
+    table = get_2d_sincos_pos_embed_from_grid(embed_dim, np.stack([cols, rows]).reshape(2, 1, grid_size, grid_size))
+    if cls_token and extra_tokens > 0:
+        table = np.concatenate([np.zeros([extra_tokens, embed_dim]), table], axis=0)
+    return table
 
 
 # ---- configurations (:319-372)
@@ -143,9 +149,4 @@ def DiT_S_4(**kwargs): return DiT(depth=12, hidden_size=384, patch_size=4, num_h
 def DiT_S_8(**kwargs): return DiT(depth=12, hidden_size=384, patch_size=8, num_heads=6, **kwargs)
 
 
-DiT_models = {
-    'DiT-XL/2': DiT_XL_2, 'DiT-XL/4': DiT_XL_4, 'DiT-XL/8': DiT_XL_8,
-    'DiT-L/2': DiT_L_2, 'DiT-L/4': DiT_L_4, 'DiT-L/8': DiT_L_8,
-    'DiT-B/2': DiT_B_2, 'DiT-B/4': DiT_B_4, 'DiT-B/8': DiT_B_8,
-    'DiT-S/2': DiT_S_2, 'DiT-S/4': DiT_S_4, 'DiT-S/8': DiT_S_8,
-}
+DiT_models = {f"DiT-{size}/{patch}": globals()[f"DiT_{size}_{patch}"] for size in ("XL", "L", "B", "S") for patch in (2, 4, 8)}

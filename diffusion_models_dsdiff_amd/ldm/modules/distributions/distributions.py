@@ -44,19 +44,22 @@ class DiagonalGaussianDistribution(object):
         check(lib().dsd_op_gaussian_sample(dptr(p), dptr(noise), C.c_uint64(seed), B, E2 // 2, H, W, dptr(z), stream_ptr()))
         return z
 
+    # The two closed forms the training loss uses (:39-58); plain torch on whatever device the moments live on.
     def kl(self, other=None):
+        """KL(self || other) per sample, ``other`` = the standard normal when omitted."""
         if self.deterministic:
             return torch.Tensor([0.])
         if other is None:
-            return 0.5 * torch.sum(torch.pow(self.mean, 2) + self.var - 1.0 - self.logvar, dim=[1, 2, 3])
-        return 0.5 * torch.sum(torch.pow(self.mean - other.mean, 2) / other.var + self.var / other.var - 1.0 - self.logvar
-                               + other.logvar, dim=[1, 2, 3])
+            terms = self.mean.pow(2) + self.var - 1.0 - self.logvar
+        else:
+            terms = (self.mean - other.mean).pow(2) / other.var + self.var / other.var - 1.0 - self.logvar + other.logvar
+        return 0.5 * terms.sum(dim=[1, 2, 3])
 
     def nll(self, sample, dims=[1, 2, 3]):
+        """Negative log-likelihood of ``sample`` under this Gaussian, summed over ``dims``."""
         if self.deterministic:
             return torch.Tensor([0.])
-        logtwopi = np.log(2.0 * np.pi)
-        return 0.5 * torch.sum(logtwopi + self.logvar + torch.pow(sample - self.mean, 2) / self.var, dim=dims)
+        return 0.5 * (float(np.log(2.0 * np.pi)) + self.logvar + (sample - self.mean).pow(2) / self.var).sum(dim=dims)
 
     def mode(self):
         return self.mean

@@ -92,3 +92,21 @@ def test_dit_rejects_bad_input():
         m(torch.zeros(1, 4, 16, 16).cuda(), torch.tensor([1.0]).cuda(), torch.tensor([0]).cuda())   # labels without a table
     with pytest.raises(_lib.DsdError):
         m(torch.zeros(1, 4, 16, 16), torch.tensor([1.0]))                       # CPU tensors
+
+
+def test_forward_with_cfg_composition():
+    """forward_with_cfg (:245-262): the guided estimate on the first three channels, both halves equal, rest passed through —
+    written out from plain forward() calls."""
+    m, _ = make(input_size=16, patch_size=2, in_channels=6, hidden_size=64, depth=2, num_heads=4, num_classes=3, learn_sigma=True)
+    n = 2
+    x = randn((2 * n, 6, 16, 16), 31).cuda()
+    t = torch.tensor([10.0, 500.0, 10.0, 500.0]).cuda()
+    y = torch.tensor([1, 2, 3, 3]).cuda()                       # second half: the null label (= num_classes)
+    s = 2.5
+    got = m.forward_with_cfg(x, t, y, s)
+    full = m(torch.cat([x[:n], x[:n]]), t, y)
+    assert got.shape == full.shape
+    e_c, e_u = full[:n, :3], full[n:, :3]
+    want_eps = e_u + s * (e_c - e_u)
+    assert torch.allclose(got[:n, :3], want_eps, rtol=0, atol=0) and torch.equal(got[:n, :3], got[n:, :3])
+    assert torch.equal(got[:, 3:], full[:, 3:])
