@@ -31,7 +31,8 @@
 // registers (DMA = true, DSD_CONV_DMA): no difference (228 vs 228 TF/s), the DMA piece costs the issue slots the
 // register path's load + ds_write did.  Weight-tile loads non-temporal (what-if 128, so that they do not push the
 // activation lines the next filter tap re-reads out of the 32 KB L1): clock 1.81 -> 1.78 GHz, +1.5 % time (the tiles then
-// miss L2 as well).
+// miss L2 as well).  Activations pre-split in memory as three bf16 planes (what-if 256: 12 piece loads per tile and lane
+// instead of 8, no split VALU): 6187 cycles per k-tile, +15 % time — the VALU it saves was hidden, the loads it adds are not.
 //
 // Tiling is the fp32 kernel's (conv.hip): 256 threads, 128 x 32*NT x 32 block tile, wave = 32 rows x NT column tiles,
 // buffer loads with hardware range checks, register prefetch of the next tile, fused bias/embedding/residual epilogue.
@@ -521,6 +522,16 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
     // (what-if bit 128) weight-tile loads non-temporal: a tile is read once per CU and need not displace the activation
     // lines, which the next filter tap re-reads, from the 32 KB L1
     constexpr int B_AUX = (WI & 128) ? 2 : 0;
+    // (what-if bit 256) VERDICT r1 item 5a, the convolution's side of it: activations arrive PRE-SPLIT as three bf16 planes
+    // (6 B per element) — per tile and lane 12 loads of 16 B instead of 8 and no split VALU in the loop.  Timing only: the
+    // planes are faked inside the fp32 tensor (same pixel stride in elements, a third of the buffer apart).
+    constexpr bool PRESPLIT = (WI & 256) != 0;
+    const unsigned pplane = (p.x_bytes / 4u) & ~255u;
+    u32x4 rp[RB][6];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) rp[r][q] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
     auto stamp = [&](int i) {
         if (STAMP && threadIdx.x == 0) {
             p.stamps[(size_t)blockIdx.x * 8 + 2 * i] = clock_core();
@@ -799,6 +810,19 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
                 for (int t = 0; t < NTASK; ++t) {
                     if (t * NT / NTASK != j) continue;
                     const int r = t / 4, i = t % 4;
+                    if (PRESPLIT) {   // (diagnostic) the pieces come from memory: 6 loads of 16 B instead of 4 + the split
+                        if (t == 0) soff_as = __builtin_amdgcn_readfirstlane(min(cc, p.cchunks - 1) * (SBK * 2));
+                        if (i == 1 || i == 3) {
+                            bf16x8 (&dst)[NP] = i == 1 ? af[0][r] : afn1[r];
+#pragma unroll
+                            for (int q = 0; q < NP; ++q) dst[q] = __builtin_bit_cast(bf16x8, rp[r][(i >> 1) * 3 + q]);
+#pragma unroll
+                            for (int q = 0; q < NP; ++q)   // piece plane q, k-step i >> 1: the fp32 element offset halved
+                                rp[r][(i >> 1) * 3 + q] = __builtin_amdgcn_raw_buffer_load_b128(
+                                    rx, a_voff[r][0] == OOB ? OOB : (a_voff[r][0] >> 1) + (unsigned)q * pplane + (unsigned)(i >> 1) * 32u, soff_as, 0);
+                        }
+                        continue;
+                    }
                     if (i == 0) sp4(ra[r][0], pl);
                     if (i == 1) {
                         sp4(ra[r][1], ph);
@@ -943,7 +967,8 @@ static void launch_split(const SplitP& p, int nt, hipStream_t s, int ad) {   // 
             case 16: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 17>), grid, dim3(256), 0, s, p); break;
             case 31: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 32>), grid, dim3(256), 0, s, p); break;
             case 32: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 33>), grid, dim3(256), 0, s, p); break;
-            default: fail("conv stamps: what-if %d is not instantiated in this build (0, 2, 4, 8, 16, 31, 32 are; 1, 3, 64, 128 were measured in round 2 and their cases removed to keep the build short: add the case back to re-measure)", p.diag);
+            case 256: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 257>), grid, dim3(256), 0, s, p); break;
+            default: fail("conv stamps: what-if %d is not instantiated in this build (0, 2, 4, 8, 16, 31, 32, 256 are; 1, 3, 64, 128 were measured in round 2 and their cases removed to keep the build short: add the case back to re-measure)", p.diag);
         }
         check_launch("conv_split_ad2_stamped");
         return;

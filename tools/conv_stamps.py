@@ -12,7 +12,8 @@ whatifs = [int(v) for v in os.environ.get("DSD_WHATIF", "0").split(",")]
 cap = 1 << 16
 WHAT = {0: "product kernel", 2: "no activation loads", 4: "no weight loads / LDS writes",
         8: "no barrier", 16: "no weight fragment reads", 31: "bare MFMA stream of this kernel",
-        32: "loads issued in bursts of eight (the schedule before r2; correct results)"}
+        32: "loads issued in bursts of eight (the schedule before r2; correct results)",
+        256: "activations pre-split in memory: 12 piece loads per tile, no split VALU (VERDICT r1 item 5a, conv side)"}
 for wi in whatifs:
   buf = np.zeros((cap, 8), dtype=np.int64)
   n = C.c_int()
