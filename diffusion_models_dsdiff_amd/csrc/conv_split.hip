@@ -511,7 +511,13 @@ static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, unsig
 // DIAG > 0 = diagnostic instantiations (never on the product path): clock stamps around prologue / k-loop / epilogue, and
 // with what-if bits DIAG - 1 one cost of the loop removed (results are then garbage): 1 no activation split (raw bits),
 // 2 no activation loads, 4 no weight loads / LDS writes, 8 no barrier, 16 no weight fragment reads from LDS.
-template <int NT, int NP, bool F16, int RB, bool DMA = false, int DIAG = 0>
+// TR ("tap reuse", 3x3 stride-1 layers on the 256-row tile): the activations of ONE filter row — the tile's pixels of input
+// row oh + kh - 1 plus a zero column on either side, 32 channels, fp32 — come into LDS once by LDS-DMA and serve the three
+// taps kw = 0, 1, 2, which differ only by a one-pixel shift of the read address.  Per k-tile and wave that is 3 instead
+// of 8 activation load instructions (each costs ~50 cycles of the wave's only issue stream, what-if table above) and a
+// third of the activation bytes from L2; lanes fetch their 32-byte fragments from LDS (128-byte rows, the eight 16-byte
+// chunks XOR-swizzled with (row >> 1) & 7 through the DMA's source address) and split them as before.
+template <int NT, int NP, bool F16, int RB, bool DMA = false, int DIAG = 0, bool TR = false>
 __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(SplitP p) {
     constexpr bool STAMP = DIAG > 0;
     constexpr int WI = DIAG > 0 ? DIAG - 1 : 0;
@@ -549,8 +555,12 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
     // barrier of tile kt since).  The last 16 B x 256 are per-thread dummy slots: the threads of the final, partly filled
     // staging round write there instead of branching on the exec mask.
     constexpr int STAGE = NP * B_PLANE;
-    static_assert((2 * STAGE + 4096) * (RB == 1 ? 2 : 1) <= 160 * 1024, "both weight stages of the resident workgroups must fit the LDS");
-    __shared__ __attribute__((aligned(1024))) unsigned char Bs[2 * STAGE + 256 * 16];
+    constexpr int A_ROWS = 272;                      // >= segments * (W + 2) for W = 32 .. 256 (8 x 34), a multiple of 8
+    constexpr int A_STAGE = A_ROWS * 128;            // one filter row of the tile: [entry][32 channels fp32]
+    constexpr int A_OFF = 2 * STAGE + 256 * 16;
+    static_assert(!TR || (RB == 2 && !DMA && NT == 5), "tap reuse is built for the 256 x 160 tile with the register weight path (one DMA round per unit)");
+    static_assert((A_OFF + (TR ? 2 * A_STAGE : 0)) * (RB == 1 ? 2 : 1) <= 160 * 1024, "the stages of the resident workgroups must fit the LDS");
+    __shared__ __attribute__((aligned(1024))) unsigned char Bs[A_OFF + (TR ? 2 * A_STAGE : 0)];
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
@@ -629,6 +639,43 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         b_lds[i] = piece < NP ? piece * B_PLANE + row * RS + ch * 16 : -1;
     }
     const int b_dummy = 2 * STAGE + tid * 16;
+    // ---- tap reuse: entry (= LDS row) of this lane's pixels for kw = 0, and the DMA role of this thread
+    // entry of pixel (segment sg, column ow) under tap kw: sg * (W + 2) + ow + kw   (entry 0 / W + 1 of a segment = padding)
+    int a_ent[RB];
+    unsigned d_off[9];      // byte offset of (sample, input row oh(segment) - 1, column, swizzled 16-byte chunk), mod 2^32
+    int d_oh[9];
+    unsigned d_ok = 0;      // bit i: round i of this thread is a real pixel column of a segment of the tile
+    const unsigned rowpitch = (unsigned)p.W * (unsigned)p.Cin * 4u;
+    if (TR) {
+        const int Wp = p.OW + 2;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int lm = (wave * RB + r) * 32 + lrow;
+            a_ent[r] = (lm / p.OW) * Wp + lm % p.OW;
+        }
+        const int nb = m0 / p.ohw;
+        const int oh0 = (m0 - nb * p.ohw) / p.OW;
+        const int segs = (SBM * RB) / p.OW;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int q = i * 256 + tid;
+            const int entry = q >> 3;
+            const int sg = entry / Wp, col = entry - sg * Wp - 1;
+            const bool ok = sg < segs && (unsigned)col < (unsigned)p.OW;
+            const int lc = (q & 7) ^ ((entry >> 1) & 7);   // the logical chunk this physical slot holds
+            d_oh[i] = oh0 + sg - 1;
+            d_off[i] = ((unsigned)nb * (unsigned)p.x_bs + (unsigned)((oh0 + sg - 1) * p.W + col) * (unsigned)p.Cin) * 4u + (unsigned)(lc * 16);
+            d_ok |= ok ? 1u << i : 0u;
+        }
+    }
+    // round i of the DMA of filter row (c2, h2) into its stage: rows whose input row lies outside the image, the padding
+    // columns and the unused tail of the stage get OOB addresses, i.e. zeros
+    auto dma_a = [&](int i, int c2, int h2) {
+        if (i * 4096 + wave * 1024 >= A_STAGE) return;
+        const int ih = d_oh[i] + h2;
+        const unsigned v = ((d_ok >> i) & 1u) && (unsigned)ih < (unsigned)p.H ? d_off[i] + (unsigned)h2 * rowpitch : OOB;
+        lds_dma16(rx, Bs + A_OFF + ((c2 + h2) & 1) * A_STAGE + i * 4096 + wave * 1024, v, __builtin_amdgcn_readfirstlane(c2 * (SBK * 4)));
+    };
     f32x4 ra[RB][4];   // [row block][k-step lo/hi 4 floats]
     u32x4 rb[NBL];
 
@@ -740,13 +787,31 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
             split4<NP, F16>(v, out, p.ovf);
         }
     };
+    // tap reuse: the four 16-byte pieces of row block r for the tile the counters (cc, kh, kw) point at
+    auto lds_a = [&](int r, int i) {
+        const int e = a_ent[r] + kw;
+        const int ch = (i < 2 ? 0 : 4) + half * 2 + (i & 1);
+        ra[r][i] = *reinterpret_cast<const f32x4*>(Bs + A_OFF + ((cc + kh) & 1) * A_STAGE + e * 128 + ((ch ^ ((e >> 1) & 7)) << 4));
+    };
+    int kw_cur = 0, kh_cur = 0, cc_cur = 0;   // (tap reuse) the tile being multiplied; the DMA of the NEXT filter row starts at kw_cur == 0
     bf16x8 af[2][RB][NP];   // A fragments of the current tile (both k-steps), in registers
     bf16x8 afn1[RB][NP];    // second k-step of the next tile (af[1] is live until the last unit)
     // prologue: tile 0 -> af / LDS stage 0, tile 1 -> ra / rb in flight
-    tap_offsets(kh, kw);
+    if (TR) {   // filter row (0, 0) into its stage; its successor follows from inside the loop
 #pragma unroll
-    for (int r = 0; r < RB; ++r) load_a(r);
-    if (DMA) dma_b(0); else load_b();
+        for (int i = 0; i < 9; ++i) dma_a(i, 0, 0);
+        if (DMA) dma_b(0); else load_b();
+        __syncthreads();   // (waits for the DMA: vmcnt(0) in front of the barrier)
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds_a(r, i);
+    } else {
+        tap_offsets(kh, kw);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) load_a(r);
+        if (DMA) dma_b(0); else load_b();
+    }
 #pragma unroll
     for (int r = 0; r < RB; ++r) {
         split8<NP, F16>(ra[r][0], ra[r][1], af[0][r], p.ovf);
@@ -757,9 +822,16 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         for (int i = 0; i < NBL; ++i) store_b(i, 0);
     }
     advance();
-    tap_offsets(kh, kw);
+    if (TR) {
 #pragma unroll
-    for (int r = 0; r < RB; ++r) load_a(r);
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lds_a(r, i);
+    } else {
+        tap_offsets(kh, kw);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) load_a(r);
+    }
     if (!DMA) load_b();
 
     stamp(1);
@@ -783,6 +855,11 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
                     if (!(WI & 16)) b_nxt[q] = *reinterpret_cast<const bf16x8*>(bf + q * B_PLANE + j1 * 32 * RS + foff[s1]);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (TR && u < 9) {   // first tile of a filter row: one DMA round of the NEXT filter row per unit (uniform branch)
+                const bool wrap = kh_cur == 2;
+                const int c2 = wrap ? cc_cur + 1 : cc_cur, h2 = wrap ? 0 : kh_cur + 1;
+                if (kw_cur == 0 && c2 < p.cchunks) dma_a(u, c2, h2);
+            }
             if (s == 0 && SPREAD) {   // as below, but each staging register is re-loaded (tile kt+2) right after its LDS write
                 if (j == 0) {
                     advance();
@@ -805,7 +882,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
                     if (!DMA) load_b();
                 }
             } else {        // activations of tile kt+1 -> pieces, task t = (row block, 4-float slot) in unit t*NT/NTASK
-                if (j == 0) tap_offsets(kh, kw);   // of the tile advance() moved to; its loads follow once ra is free
+                if (j == 0 && !TR) tap_offsets(kh, kw);   // of the tile advance() moved to; its loads follow once ra is free
 #pragma unroll
                 for (int t = 0; t < NTASK; ++t) {
                     if (t * NT / NTASK != j) continue;
@@ -834,7 +911,9 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
                         join(pl, ph, afn1[r]);
                         if (!SPREAD) load_a(r);
                     }
-                    if (SPREAD) {   // each 16-byte piece is re-loaded (tile kt+2) as soon as it has been split
+                    if (TR) {       // ... from the filter row in LDS (past the last tile: a stale stage, never multiplied)
+                        lds_a(r, i);
+                    } else if (SPREAD) {   // each 16-byte piece is re-loaded (tile kt+2) as soon as it has been split
                         if (t == 0) soff_as = __builtin_amdgcn_readfirstlane(min(cc, p.cchunks - 1) * (SBK * 4));
                         ra[r][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[r][i], soff_as, 0));
                     }
@@ -850,6 +929,12 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int q = 0; q < NP; ++q) af[1][r][q] = afn1[r][q];
+        if (TR) {   // the tile just multiplied -> its successor (scalar selects)
+            const bool ww = kw_cur == 2, wh = ww && kh_cur == 2;
+            kw_cur = ww ? 0 : kw_cur + 1;
+            kh_cur = ww ? (wh ? 0 : kh_cur + 1) : kh_cur;
+            cc_cur += wh ? 1 : 0;
+        }
     }
     stamp(2);
     if (p.ksplit > 1) {   // raw partial sums; bias / embedding / residual are added once, by the reduction
@@ -954,6 +1039,15 @@ static bool conv_dma_enabled() {
     return on;
 }
 
+// tap reuse (TR instantiation): 3x3, stride 1, "same" padding, no folded upsample, unsplit K; the 256-row tile is a whole
+// number of image rows of one sample (W = 32 .. 256 a power of two, H * W a multiple of 256)
+static bool conv_tr_ok(const SplitP& p) {
+    static const int mode = getenv("DSD_CONV_TR") ? atoi(getenv("DSD_CONV_TR")) : 0;   // experiment switch
+    if (mode <= 0) return false;
+    return p.ks == 3 && p.stride == 1 && p.ups == 0 && p.pad == 1 && p.OW == p.W && p.OH == p.H && p.ksplit == 1 && !p.out_nchw &&
+           (p.W == 32 || p.W == 64 || p.W == 128 || p.W == 256) && p.ohw % (2 * SBM) == 0 && p.M % (2 * SBM) == 0 && p.Cin % SBK == 0;
+}
+
 template <int NP, bool F16>
 static void launch_split(const SplitP& p, int nt, hipStream_t s, int ad) {   // ad: 0 = staged, 1 / 2 = A-direct with RB row blocks
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (ad >= 1 ? p.ksplit : 1)));
@@ -968,9 +1062,15 @@ static void launch_split(const SplitP& p, int nt, hipStream_t s, int ad) {   // 
             case 31: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 32>), grid, dim3(256), 0, s, p); break;
             case 32: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 33>), grid, dim3(256), 0, s, p); break;
             case 256: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 257>), grid, dim3(256), 0, s, p); break;
+            case 512: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 1, true>), grid, dim3(256), 0, s, p); break;
             default: fail("conv stamps: what-if %d is not instantiated in this build (0, 2, 4, 8, 16, 31, 32, 256 are; 1, 3, 64, 128 were measured in round 2 and their cases removed to keep the build short: add the case back to re-measure)", p.diag);
         }
         check_launch("conv_split_ad2_stamped");
+        return;
+    }
+    if (ad == 2 && nt == 5 && NP == 3 && !F16 && conv_tr_ok(p)) {
+        hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 0, true>), grid, dim3(256), 0, s, p);
+        check_launch("conv_split_ad2_tr");
         return;
     }
     if (ad == 2 && conv_dma_enabled() && nt == 5 && NP == 3 && !F16) {

@@ -335,3 +335,34 @@ def test_diagnostic_entry_points():
     assert L.dsd_bench_conv2d_stamps(1, 256, 256, 320, 320, 0, 5, buf.ctypes.data_as(C.POINTER(C.c_longlong)), 512, C.byref(n)) != 0   # not instantiated
     assert L.dsd_bench_conv2d_stamps(1, 256, 256, 320, 320, 0, 0, buf.ctypes.data_as(C.POINTER(C.c_longlong)), 8, C.byref(n)) != 0     # too little room
     assert L.dsd_bench_conv2d_stamps(1, 64, 64, 320, 320, 0, 0, buf.ctypes.data_as(C.POINTER(C.c_longlong)), 512, C.byref(n)) != 0     # split-K shape: no diagnostic build
+
+
+TR_CASES = [
+    # N, H, W, Cin, Cout: 3x3 stride-1 layers whose 256-row tiles are whole image rows and whose grid keeps the 160-column
+    # tile (the shape class the tap-reuse instantiation of the A-direct kernel takes: conv_split.hip, TR)
+    (1, 256, 256, 32, 320),      # one image row per tile; first / last rows and columns are the zero padding
+    (2, 128, 128, 64, 320),      # two rows per tile
+    (8, 64, 64, 32, 160),        # four rows per tile, a single column tile
+    (32, 32, 32, 96, 320),       # eight rows per tile = a quarter of a sample; 27 k-tiles, three channel chunks
+    (4, 64, 128, 64, 320),       # non-square
+]
+
+
+@pytest.mark.parametrize("case", TR_CASES)
+def test_conv2d_row_tiles(ops, case):
+    """bf16x6 on the large 3x3 layers, every epilogue fusion on, against float64 — the kernel structure is the library's
+    choice (with tap reuse enabled these shapes run the TR instantiation)."""
+    N, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(sum(case) + 5)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    emb = torch.randn(N, Cout, generator=g)
+    res = torch.randn(N, Cout, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + emb.double()[:, :, None, None] + res.double()
+    y = ops.conv2d(cu(ops.to_nhwc(x)), cu(w), cu(b), emb=cu(emb), res=cu(ops.to_nhwc(res)), precision="bf16x6")
+    assert rel_l2(ops.to_nchw(y), ref) < PREC_TOL["bf16x6"], case
+    # border pixels exactly where the padding matters
+    yy, rr = ops.to_nchw(y).double().cpu(), ref
+    for sl in ((..., 0, slice(None)), (..., H - 1, slice(None)), (..., slice(None), 0), (..., slice(None), W - 1)):
+        assert rel_l2(yy[sl], rr[sl]) < PREC_TOL["bf16x6"], (case, sl)
