@@ -42,6 +42,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace dsd {
 
@@ -511,12 +512,22 @@ static __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t r, unsig
 // DIAG > 0 = diagnostic instantiations (never on the product path): clock stamps around prologue / k-loop / epilogue, and
 // with what-if bits DIAG - 1 one cost of the loop removed (results are then garbage): 1 no activation split (raw bits),
 // 2 no activation loads, 4 no weight loads / LDS writes, 8 no barrier, 16 no weight fragment reads from LDS.
-// TR ("tap reuse", 3x3 stride-1 layers on the 256-row tile): the activations of ONE filter row — the tile's pixels of input
-// row oh + kh - 1 plus a zero column on either side, 32 channels, fp32 — come into LDS once by LDS-DMA and serve the three
-// taps kw = 0, 1, 2, which differ only by a one-pixel shift of the read address.  Per k-tile and wave that is 3 instead
-// of 8 activation load instructions (each costs ~50 cycles of the wave's only issue stream, what-if table above) and a
-// third of the activation bytes from L2; lanes fetch their 32-byte fragments from LDS (128-byte rows, the eight 16-byte
-// chunks XOR-swizzled with (row >> 1) & 7 through the DMA's source address) and split them as before.
+// TR ("tap reuse", 3x3 stride-1 layers on the 256-row tile): the activations of ONE filter row — the tile's 256 pixels of
+// input row oh + kh - 1, 32 channels, fp32 — are staged in LDS once (global -> registers -> LDS, like the weights, a whole
+// tile ahead) and serve the three taps kw = 0, 1, 2, which differ only by a one-pixel shift of the LDS read address (a lane
+// whose shifted pixel falls off its image row reads a row of zeros).  Per k-tile and wave that is 2.7 instead of 8
+// activation load instructions (each costs ~50 cycles of the wave's only issue stream, what-if table above) and a third
+// of the activation bytes from L2; lanes fetch their 16-byte pieces from LDS one unit ahead of the split that consumes
+// them (128-byte rows, the eight 16-byte chunks XOR-swizzled with (row >> 1) & 7: conflict-free reads and writes).
+// Measured (16x256x256x320->320 and the other large layers, same box): 230.6 vs 226.1, 237.5 vs 233.0, 231.0 vs 226.8 TF/s;
+// whole step 435.1 vs 441.1 ms (-1.4 %).  The cycle count per k-tile stays (4757 vs 4766) — the issue slots of the saved
+// loads go to the extra LDS traffic — the gain is the clock (1.78 vs 1.755 GHz: fewer bytes from L2).  What-ifs on THIS
+// kernel (profiles/r02_conv_stamps_tr_whatif.txt): no weight loads / LDS writes 4383 cycles, -7.5 % time at the same clock;
+// no barrier 4625 cycles but 1.745 GHz, -1 %; no weight fragment reads 4733 cycles at 1.82 GHz, -2 %.
+// Two things that did NOT work on the way: staging by LDS-DMA (the stage then needs padding entries, and every barrier
+// waits for the DMA: +15 % cycles, profiles/r02_conv_stamps_tr_dma.txt), and uniform branches ("first tile of a filter
+// row?") inside the unit loop — the IR then has several blocks per tile and the compiler sinks the whole split into the last
+// one (5564 cycles); the loop is therefore unrolled by three with the tap column a compile-time constant.
 template <int NT, int NP, bool F16, int RB, bool DMA = false, int DIAG = 0, bool TR = false>
 __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(SplitP p) {
     constexpr bool STAMP = DIAG > 0;
@@ -555,10 +566,9 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
     // barrier of tile kt since).  The last 16 B x 256 are per-thread dummy slots: the threads of the final, partly filled
     // staging round write there instead of branching on the exec mask.
     constexpr int STAGE = NP * B_PLANE;
-    constexpr int A_ROWS = 272;                      // >= segments * (W + 2) for W = 32 .. 256 (8 x 34), a multiple of 8
-    constexpr int A_STAGE = A_ROWS * 128;            // one filter row of the tile: [entry][32 channels fp32]
+    constexpr int A_STAGE = 257 * 128;               // one filter row of the tile: [pixel][32 channels fp32] + a row of zeros
     constexpr int A_OFF = 2 * STAGE + 256 * 16;
-    static_assert(!TR || (RB == 2 && !DMA && NT == 5), "tap reuse is built for the 256 x 160 tile with the register weight path (one DMA round per unit)");
+    static_assert(!TR || (RB == 2 && !DMA && NT == 5), "tap reuse is built for the 256 x 160 tile with the register weight path");
     static_assert((A_OFF + (TR ? 2 * A_STAGE : 0)) * (RB == 1 ? 2 : 1) <= 160 * 1024, "the stages of the resident workgroups must fit the LDS");
     __shared__ __attribute__((aligned(1024))) unsigned char Bs[A_OFF + (TR ? 2 * A_STAGE : 0)];
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
@@ -639,42 +649,38 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         b_lds[i] = piece < NP ? piece * B_PLANE + row * RS + ch * 16 : -1;
     }
     const int b_dummy = 2 * STAGE + tid * 16;
-    // ---- tap reuse: entry (= LDS row) of this lane's pixels for kw = 0, and the DMA role of this thread
-    // entry of pixel (segment sg, column ow) under tap kw: sg * (W + 2) + ow + kw   (entry 0 / W + 1 of a segment = padding)
-    int a_ent[RB];
-    unsigned d_off[9];      // byte offset of (sample, input row oh(segment) - 1, column, swizzled 16-byte chunk), mod 2^32
-    int d_oh[9];
-    unsigned d_ok = 0;      // bit i: round i of this thread is a real pixel column of a segment of the tile
+    // ---- tap reuse: this lane's pixels inside the tile, and the staging role of this thread
+    int a_lm[RB], a_ow[RB];
+    unsigned g_off[8];      // byte offset of (sample, input row oh(pixel) - 1, column, the 16-byte chunk this slot holds), mod 2^32
+    int g_oh[8];
     const unsigned rowpitch = (unsigned)p.W * (unsigned)p.Cin * 4u;
     if (TR) {
-        const int Wp = p.OW + 2;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
-            const int lm = (wave * RB + r) * 32 + lrow;
-            a_ent[r] = (lm / p.OW) * Wp + lm % p.OW;
+            a_lm[r] = (wave * RB + r) * 32 + lrow;
+            a_ow[r] = a_lm[r] % p.OW;
         }
         const int nb = m0 / p.ohw;
         const int oh0 = (m0 - nb * p.ohw) / p.OW;
-        const int segs = (SBM * RB) / p.OW;
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int q = i * 256 + tid;
-            const int entry = q >> 3;
-            const int sg = entry / Wp, col = entry - sg * Wp - 1;
-            const bool ok = sg < segs && (unsigned)col < (unsigned)p.OW;
-            const int lc = (q & 7) ^ ((entry >> 1) & 7);   // the logical chunk this physical slot holds
-            d_oh[i] = oh0 + sg - 1;
-            d_off[i] = ((unsigned)nb * (unsigned)p.x_bs + (unsigned)((oh0 + sg - 1) * p.W + col) * (unsigned)p.Cin) * 4u + (unsigned)(lc * 16);
-            d_ok |= ok ? 1u << i : 0u;
+        for (int i = 0; i < 8; ++i) {
+            const int q = i * 256 + tid;        // LDS slot: pixel q >> 3, physical chunk q & 7
+            const int px = q >> 3;
+            const int lc = (q & 7) ^ ((px >> 1) & 7);
+            const int sg = px / p.OW, col = px - sg * p.OW;
+            g_oh[i] = oh0 + sg - 1;
+            g_off[i] = ((unsigned)nb * (unsigned)p.x_bs + (unsigned)((oh0 + sg - 1) * p.W + col) * (unsigned)p.Cin) * 4u + (unsigned)(lc * 16);
         }
     }
-    // round i of the DMA of filter row (c2, h2) into its stage: rows whose input row lies outside the image, the padding
-    // columns and the unused tail of the stage get OOB addresses, i.e. zeros
-    auto dma_a = [&](int i, int c2, int h2) {
-        if (i * 4096 + wave * 1024 >= A_STAGE) return;
-        const int ih = d_oh[i] + h2;
-        const unsigned v = ((d_ok >> i) & 1u) && (unsigned)ih < (unsigned)p.H ? d_off[i] + (unsigned)h2 * rowpitch : OOB;
-        lds_dma16(rx, Bs + A_OFF + ((c2 + h2) & 1) * A_STAGE + i * 4096 + wave * 1024, v, __builtin_amdgcn_readfirstlane(c2 * (SBK * 4)));
+    u32x4 stg[8];           // (tap reuse) the next filter row on its way global -> LDS
+    // loads of filter row (c2, h2); a pixel whose input row lies outside the image gets an out-of-range address, i.e. zeros
+    auto load_row = [&](int i, int c2, int h2) {
+        const int ih = g_oh[i] + h2;
+        const unsigned v = (unsigned)ih < (unsigned)p.H ? g_off[i] + (unsigned)h2 * rowpitch : OOB;
+        stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, v, __builtin_amdgcn_readfirstlane(min(c2, p.cchunks - 1) * (SBK * 4)), 0);
+    };
+    auto store_row = [&](int i, int c2, int h2) {
+        *reinterpret_cast<u32x4*>(Bs + A_OFF + ((c2 + h2) & 1) * A_STAGE + (i * 256 + tid) * 16) = stg[i];
     };
     f32x4 ra[RB][4];   // [row block][k-step lo/hi 4 floats]
     u32x4 rb[NBL];
@@ -787,25 +793,30 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
             split4<NP, F16>(v, out, p.ovf);
         }
     };
-    // tap reuse: the four 16-byte pieces of row block r for the tile the counters (cc, kh, kw) point at
-    auto lds_a = [&](int r, int i) {
-        const int e = a_ent[r] + kw;
+    // tap reuse: 16-byte piece i of row block r under tap kw2 from the filter row with stage parity par
+    auto lds_piece = [&](int r, int i, int par, int kw2) -> f32x4 {
+        const bool in = (unsigned)(a_ow[r] + kw2 - 1) < (unsigned)p.OW;
+        const int row = in ? a_lm[r] + kw2 - 1 : 256;   // 256 = the row of zeros
         const int ch = (i < 2 ? 0 : 4) + half * 2 + (i & 1);
-        ra[r][i] = *reinterpret_cast<const f32x4*>(Bs + A_OFF + ((cc + kh) & 1) * A_STAGE + e * 128 + ((ch ^ ((e >> 1) & 7)) << 4));
+        return *reinterpret_cast<const f32x4*>(Bs + A_OFF + par * A_STAGE + row * 128 + ((ch ^ ((row >> 1) & 7)) << 4));
     };
-    int kw_cur = 0, kh_cur = 0, cc_cur = 0;   // (tap reuse) the tile being multiplied; the DMA of the NEXT filter row starts at kw_cur == 0
+    int kh_cur = 0, cc_cur = 0;               // (tap reuse) filter row of the tile being multiplied
+    f32x4 a_nx[1];                            // (tap reuse) the piece read from LDS one unit ahead of its split
     bf16x8 af[2][RB][NP];   // A fragments of the current tile (both k-steps), in registers
     bf16x8 afn1[RB][NP];    // second k-step of the next tile (af[1] is live until the last unit)
     // prologue: tile 0 -> af / LDS stage 0, tile 1 -> ra / rb in flight
-    if (TR) {   // filter row (0, 0) into its stage; its successor follows from inside the loop
+    if (TR) {   // filter row (0, 0) -> stage 0, the zero rows of both stages; its successors follow from inside the loop
 #pragma unroll
-        for (int i = 0; i < 9; ++i) dma_a(i, 0, 0);
+        for (int i = 0; i < 8; ++i) load_row(i, 0, 0);
         if (DMA) dma_b(0); else load_b();
-        __syncthreads();   // (waits for the DMA: vmcnt(0) in front of the barrier)
+        if (tid < 16) *reinterpret_cast<u32x4*>(Bs + A_OFF + (tid >> 3) * A_STAGE + 256 * 128 + (tid & 7) * 16) = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) store_row(i, 0, 0);
+        __syncthreads();
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lds_a(r, i);
+            for (int i = 0; i < 4; ++i) ra[r][i] = lds_piece(r, i, 0, 0);
     } else {
         tap_offsets(kh, kw);
 #pragma unroll
@@ -822,12 +833,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         for (int i = 0; i < NBL; ++i) store_b(i, 0);
     }
     advance();
-    if (TR) {
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) lds_a(r, i);
-    } else {
+    if (!TR) {
         tap_offsets(kh, kw);
 #pragma unroll
         for (int r = 0; r < RB; ++r) load_a(r);
@@ -835,7 +841,11 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
     if (!DMA) load_b();
 
     stamp(1);
-    for (int kt = 0; kt < KT; ++kt) {
+    // One k-tile.  KWC: the tap column of the tile as a compile-time constant in the tap-reuse instantiation, whose loop is
+    // unrolled by three so that "first / second tile of a filter row" costs no branch (a branch inside the MFMA stream lets the
+    // compiler sink the split work of a whole tile into its last block: measured 5564 cycles per k-tile); -1 otherwise.
+    auto tile = [&](auto KWC, const int kt) __attribute__((always_inline)) {
+        constexpr int kw_cur = TR ? decltype(KWC)::value : 0;
         const int so = (kt & 1) * STAGE;
         if (!(WI & 8)) __syncthreads();   // weight tile kt is visible; every wave is done with the other stage (tile kt-1)
         if (DMA && kt + 1 < KT) dma_b(STAGE - so);   // the counters are at tile kt+1 here: a whole tile for the DMA to land
@@ -855,10 +865,35 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
                     if (!(WI & 16)) b_nxt[q] = *reinterpret_cast<const bf16x8*>(bf + q * B_PLANE + j1 * 32 * RS + foff[s1]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (TR && u < 9) {   // first tile of a filter row: one DMA round of the NEXT filter row per unit (uniform branch)
+            if (TR) {   // the NEXT filter row: loaded during the first tile of this one, written to LDS during the second
                 const bool wrap = kh_cur == 2;
                 const int c2 = wrap ? cc_cur + 1 : cc_cur, h2 = wrap ? 0 : kh_cur + 1;
-                if (kw_cur == 0 && c2 < p.cchunks) dma_a(u, c2, h2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    if (s == 1 && i * NT / 8 == j && kw_cur == 0) load_row(i, c2, h2);
+                    if (s == 0 && i * NT / 8 == j && kw_cur == 1) store_row(i, c2, h2);
+                }
+                // activations of tile kt+1 -> pieces: the filter row is in LDS already, so the split is spread over BOTH k-steps
+                // (one 16-byte piece per unit, fetched one unit ahead): units 1..4 make the second k-step's fragments (afn1),
+                // units 5..8 the first k-step's (af[0], free once this tile's first k-step is done)
+                if (u >= 1 && u <= 8) {
+                    const int t = u - 1, r = (t & 3) >> 1, i = (t < 4 ? 2 : 0) + (t & 1);
+                    if (i == 0 || i == 2) sp4(a_nx[0], pl);
+                    if (i == 1) {
+                        sp4(a_nx[0], ph);
+                        join(pl, ph, af[0][r]);
+                    }
+                    if (i == 3) {
+                        sp4(a_nx[0], ph);
+                        join(pl, ph, afn1[r]);
+                    }
+                }
+                if (u <= 7) {
+                    const int t = u, r = (t & 3) >> 1, i = (t < 4 ? 2 : 0) + (t & 1);
+                    const int kw_n = kw_cur == 2 ? 0 : kw_cur + 1;
+                    const int par_n = kw_cur == 2 ? (c2 + h2) & 1 : (cc_cur + kh_cur) & 1;
+                    a_nx[0] = lds_piece(r, i, par_n, kw_n);
+                }
             }
             if (s == 0 && SPREAD) {   // as below, but each staging register is re-loaded (tile kt+2) right after its LDS write
                 if (j == 0) {
@@ -881,8 +916,9 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
                     advance();
                     if (!DMA) load_b();
                 }
+            } else if (TR) {   // (done above)
             } else {        // activations of tile kt+1 -> pieces, task t = (row block, 4-float slot) in unit t*NT/NTASK
-                if (j == 0 && !TR) tap_offsets(kh, kw);   // of the tile advance() moved to; its loads follow once ra is free
+                if (j == 0) tap_offsets(kh, kw);   // of the tile advance() moved to; its loads follow once ra is free
 #pragma unroll
                 for (int t = 0; t < NTASK; ++t) {
                     if (t * NT / NTASK != j) continue;
@@ -911,9 +947,7 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
                         join(pl, ph, afn1[r]);
                         if (!SPREAD) load_a(r);
                     }
-                    if (TR) {       // ... from the filter row in LDS (past the last tile: a stale stage, never multiplied)
-                        lds_a(r, i);
-                    } else if (SPREAD) {   // each 16-byte piece is re-loaded (tile kt+2) as soon as it has been split
+                    if (SPREAD) {   // each 16-byte piece is re-loaded (tile kt+2) as soon as it has been split
                         if (t == 0) soff_as = __builtin_amdgcn_readfirstlane(min(cc, p.cchunks - 1) * (SBK * 4));
                         ra[r][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff[r][i], soff_as, 0));
                     }
@@ -929,12 +963,20 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int q = 0; q < NP; ++q) af[1][r][q] = afn1[r][q];
-        if (TR) {   // the tile just multiplied -> its successor (scalar selects)
-            const bool ww = kw_cur == 2, wh = ww && kh_cur == 2;
-            kw_cur = ww ? 0 : kw_cur + 1;
-            kh_cur = ww ? (wh ? 0 : kh_cur + 1) : kh_cur;
+        if (TR && kw_cur == 2) {   // last tap of a filter row -> the next filter row (scalar selects)
+            const bool wh = kh_cur == 2;
+            kh_cur = wh ? 0 : kh_cur + 1;
             cc_cur += wh ? 1 : 0;
         }
+    };
+    if (TR) {   // (K unsplit and 3 x 3: the tile count is a multiple of three and the first tile has kw = 0)
+        for (int kt = 0; kt < KT; kt += 3) {
+            tile(std::integral_constant<int, 0>{}, kt);
+            tile(std::integral_constant<int, 1>{}, kt + 1);
+            tile(std::integral_constant<int, 2>{}, kt + 2);
+        }
+    } else {
+        for (int kt = 0; kt < KT; ++kt) tile(std::integral_constant<int, -1>{}, kt);
     }
     stamp(2);
     if (p.ksplit > 1) {   // raw partial sums; bias / embedding / residual are added once, by the reduction
@@ -1042,8 +1084,8 @@ static bool conv_dma_enabled() {
 // tap reuse (TR instantiation): 3x3, stride 1, "same" padding, no folded upsample, unsplit K; the 256-row tile is a whole
 // number of image rows of one sample (W = 32 .. 256 a power of two, H * W a multiple of 256)
 static bool conv_tr_ok(const SplitP& p) {
-    static const int mode = getenv("DSD_CONV_TR") ? atoi(getenv("DSD_CONV_TR")) : 0;   // experiment switch
-    if (mode <= 0) return false;
+    static const int mode = getenv("DSD_CONV_TR") ? atoi(getenv("DSD_CONV_TR")) : 1;   // DSD_CONV_TR=0: the plain A-direct kernel (A/B)
+    if (mode <= 0 || p.stamps) return false;
     return p.ks == 3 && p.stride == 1 && p.ups == 0 && p.pad == 1 && p.OW == p.W && p.OH == p.H && p.ksplit == 1 && !p.out_nchw &&
            (p.W == 32 || p.W == 64 || p.W == 128 || p.W == 256) && p.ohw % (2 * SBM) == 0 && p.M % (2 * SBM) == 0 && p.Cin % SBK == 0;
 }
@@ -1063,7 +1105,7 @@ static void launch_split(const SplitP& p, int nt, hipStream_t s, int ad) {   // 
             case 32: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 33>), grid, dim3(256), 0, s, p); break;
             case 256: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 257>), grid, dim3(256), 0, s, p); break;
             case 512: hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 1, true>), grid, dim3(256), 0, s, p); break;
-            default: fail("conv stamps: what-if %d is not instantiated in this build (0, 2, 4, 8, 16, 31, 32, 256 are; 1, 3, 64, 128 were measured in round 2 and their cases removed to keep the build short: add the case back to re-measure)", p.diag);
+            default: fail("conv stamps: what-if %d is not instantiated in this build (0, 2, 4, 8, 16, 31, 32, 256, 512 are; 1, 3, 64, 128 were measured in round 2 and their cases removed to keep the build short: add the case back to re-measure)", p.diag);
         }
         check_launch("conv_split_ad2_stamped");
         return;

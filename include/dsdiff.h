@@ -300,7 +300,8 @@ int dsd_bench_conv2d(int N, int H, int W, int Cin, int Cout, int ks, int stride,
  * in-kernel clock.  whatif != 0 runs an instantiation with one cost of the k-loop removed (output garbage; timing only):
  * 2 no activation loads, 4 no weight loads / LDS writes, 8 no barrier, 16 no weight fragment reads, 31 all of them and no
  * activation split (the bare MFMA stream of this kernel), 32 loads issued in bursts of eight (the schedule before round 2;
- * results stay correct), 256 activations read as pre-split bf16 planes (12 piece loads per tile, no split VALU).  Other values fail (conv_split.hip lists what else was measured). */
+ * results stay correct), 256 activations read as pre-split bf16 planes (12 piece loads per tile, no split VALU), 512 the tap-reuse
+ * instantiation the library uses for these layers by default (0 stamps the plain A-direct kernel).  Other values fail (conv_split.hip lists what else was measured). */
 int dsd_bench_conv2d_stamps(int N, int H, int W, int Cin, int Cout, int warm, int whatif, long long* out, int max_wgs,
                             int* n_wgs);
 /* What the bf16 matrix pipes of this device sustain: a bare v_mfma_f32_32x32x16_bf16 loop on the dominant convolution's

@@ -13,7 +13,7 @@ cap = 1 << 16
 WHAT = {0: "product kernel", 2: "no activation loads", 4: "no weight loads / LDS writes",
         8: "no barrier", 16: "no weight fragment reads", 31: "bare MFMA stream of this kernel",
         32: "loads issued in bursts of eight (the schedule before r2; correct results)",
-        512: "tap reuse: one filter row in LDS by LDS-DMA serves the three taps (correct results)",
+        512: "tap reuse: one filter row in LDS serves the three taps (correct results)",
         256: "activations pre-split in memory: 12 piece loads per tile, no split VALU (VERDICT r1 item 5a, conv side)"}
 for wi in whatifs:
   buf = np.zeros((cap, 8), dtype=np.int64)
