@@ -651,8 +651,8 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
     const int b_dummy = 2 * STAGE + tid * 16;
     // ---- tap reuse: this lane's pixels inside the tile, and the staging role of this thread
     int a_lm[RB], a_ow[RB];
-    unsigned g_off[8];      // byte offset of (sample, input row oh(pixel) - 1, column, the 16-byte chunk this slot holds), mod 2^32
-    int g_oh[8];
+    unsigned g_off[8];      // byte offset of (sample, row 0, source column, the 16-byte chunk this slot holds)
+    int g_oh[8];            // row of the pixel above this slot's output pixel, in (upsampled) image coordinates
     const unsigned rowpitch = (unsigned)p.W * (unsigned)p.Cin * 4u;
     if (TR) {
 #pragma unroll
@@ -669,14 +669,15 @@ __global__ __launch_bounds__(256, RB == 1 ? 2 : 1) void conv_split_ad_kernel(Spl
             const int lc = (q & 7) ^ ((px >> 1) & 7);
             const int sg = px / p.OW, col = px - sg * p.OW;
             g_oh[i] = oh0 + sg - 1;
-            g_off[i] = ((unsigned)nb * (unsigned)p.x_bs + (unsigned)((oh0 + sg - 1) * p.W + col) * (unsigned)p.Cin) * 4u + (unsigned)(lc * 16);
+            g_off[i] = ((unsigned)nb * (unsigned)p.x_bs + (unsigned)(col >> p.ups) * (unsigned)p.Cin) * 4u + (unsigned)(lc * 16);
         }
     }
     u32x4 stg[8];           // (tap reuse) the next filter row on its way global -> LDS
     // loads of filter row (c2, h2); a pixel whose input row lies outside the image gets an out-of-range address, i.e. zeros
+    // (with the nearest-x2 upsample folded in, image row ih and column col read source row ih >> 1, column col >> 1)
     auto load_row = [&](int i, int c2, int h2) {
         const int ih = g_oh[i] + h2;
-        const unsigned v = (unsigned)ih < (unsigned)p.H ? g_off[i] + (unsigned)h2 * rowpitch : OOB;
+        const unsigned v = (unsigned)ih < (unsigned)p.IHg ? g_off[i] + (unsigned)(ih >> p.ups) * rowpitch : OOB;
         stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, v, __builtin_amdgcn_readfirstlane(min(c2, p.cchunks - 1) * (SBK * 4)), 0);
     };
     auto store_row = [&](int i, int c2, int h2) {
@@ -1081,13 +1082,13 @@ static bool conv_dma_enabled() {
     return on;
 }
 
-// tap reuse (TR instantiation): 3x3, stride 1, "same" padding, no folded upsample, unsplit K; the 256-row tile is a whole
+// tap reuse (TR instantiation): 3x3, stride 1, "same" padding (the folded nearest-x2 upsample included), unsplit K; the 256-row tile is a whole
 // number of image rows of one sample (W = 32 .. 256 a power of two, H * W a multiple of 256)
 static bool conv_tr_ok(const SplitP& p) {
     static const int mode = getenv("DSD_CONV_TR") ? atoi(getenv("DSD_CONV_TR")) : 1;   // DSD_CONV_TR=0: the plain A-direct kernel (A/B)
     if (mode <= 0 || p.stamps) return false;
-    return p.ks == 3 && p.stride == 1 && p.ups == 0 && p.pad == 1 && p.OW == p.W && p.OH == p.H && p.ksplit == 1 && !p.out_nchw &&
-           (p.W == 32 || p.W == 64 || p.W == 128 || p.W == 256) && p.ohw % (2 * SBM) == 0 && p.M % (2 * SBM) == 0 && p.Cin % SBK == 0;
+    return p.ks == 3 && p.stride == 1 && p.pad == 1 && p.OW == p.IWg && p.OH == p.IHg && p.ksplit == 1 && !p.out_nchw &&
+           (p.OW == 32 || p.OW == 64 || p.OW == 128 || p.OW == 256) && p.ohw % (2 * SBM) == 0 && p.M % (2 * SBM) == 0 && p.Cin % SBK == 0;
 }
 
 template <int NP, bool F16>

@@ -345,6 +345,8 @@ TR_CASES = [
     (8, 64, 64, 32, 160),        # four rows per tile, a single column tile
     (32, 32, 32, 96, 320),       # eight rows per tile = a quarter of a sample; 27 k-tiles, three channel chunks
     (4, 64, 128, 64, 320),       # non-square
+    (2, 64, 64, 32, 320, True),  # nearest x2 folded into the gather: 128 x 128 output from a 64 x 64 input
+    (1, 128, 64, 64, 160, True), # the same, non-square, 256 x 128 output
 ]
 
 
@@ -352,15 +354,18 @@ TR_CASES = [
 def test_conv2d_row_tiles(ops, case):
     """bf16x6 on the large 3x3 layers, every epilogue fusion on, against float64 — the kernel structure is the library's
     choice (with tap reuse enabled these shapes run the TR instantiation)."""
-    N, H, W, Cin, Cout = case
-    g = torch.Generator().manual_seed(sum(case) + 5)
+    N, H, W, Cin, Cout = case[:5]
+    ups = len(case) > 5 and case[5]
+    g = torch.Generator().manual_seed(sum(case[:5]) + 5)
     x = torch.randn(N, Cin, H, W, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
     b = torch.randn(Cout, generator=g)
     emb = torch.randn(N, Cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    H, W = xin.shape[2:]
     res = torch.randn(N, Cout, H, W, generator=g)
-    ref = F.conv2d(x.double(), w.double(), b.double(), padding=1) + emb.double()[:, :, None, None] + res.double()
-    y = ops.conv2d(cu(ops.to_nhwc(x)), cu(w), cu(b), emb=cu(emb), res=cu(ops.to_nhwc(res)), precision="bf16x6")
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1) + emb.double()[:, :, None, None] + res.double()
+    y = ops.conv2d(cu(ops.to_nhwc(x)), cu(w), cu(b), upsample=bool(ups), emb=cu(emb), res=cu(ops.to_nhwc(res)), precision="bf16x6")
     assert rel_l2(ops.to_nchw(y), ref) < PREC_TOL["bf16x6"], case
     # border pixels exactly where the padding matters
     yy, rr = ops.to_nchw(y).double().cpu(), ref
