@@ -175,8 +175,8 @@ def kernel_symbol(kind):
     np_, f16 = {"bf16x6": ("3", "false"), "bf16x3": ("2", "false"), "f16x3": ("2", "true")}[mode]
     if st == "/staged":
         return f"conv_split_kernel<{nt},{np_},{f16}>"
-    # (open at the end: the product instantiation carries further defaulted template arguments, "...,false,0>")
-    return f"conv_split_ad_kernel<{nt},{np_},{f16},{'1' if st == '/r128' else '2'},false,0>"
+    # (the product instantiations carry three more template arguments: LDS-DMA weights off, diagnostics off, tap reuse on / off)
+    return f"conv_split_ad_kernel<{nt},{np_},{f16},{'1' if st == '/r128' else '2'},false,0,{'true' if kind.endswith('/tr') else 'false'}>"
 
 
 def latest_pmc(precision="bf16x6"):

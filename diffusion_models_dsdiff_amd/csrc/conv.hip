@@ -674,9 +674,11 @@ const char* conv2d_variant(const ConvArgs& a) {
     conv2d_split_plan(a, nt, &nt, &ks, &ad);
     // the 256-row A-direct kernel keeps the plain name; the other structures and split-K runs are separate kinds, so that a
     // kind's average launch time is one kernel's (bench.py roofline vs the rocprofv3 kernel trace)
-    static std::string pool[4][6][3][2];
-    std::string& n = pool[pr][nt][ad][ks > 1];
-    if (n.empty()) n = std::string(names[pr][nt]) + (ad == 2 ? "" : (ad == 1 ? "/r128" : "/staged")) + (ks > 1 ? "+splitk" : "");
+    static std::string pool[4][6][3][2][2];
+    const bool tr = conv2d_split_tr(a, nt, ks, ad);   // tap reuse through LDS: an instantiation (kernel symbol) of its own
+    std::string& n = pool[pr][nt][ad][ks > 1][tr];
+    if (n.empty())
+        n = std::string(names[pr][nt]) + (ad == 2 ? "" : (ad == 1 ? "/r128" : "/staged")) + (ks > 1 ? "+splitk" : "") + (tr ? "/tr" : "");
     return n.c_str();
 }
 

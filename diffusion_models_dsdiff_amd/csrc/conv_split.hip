@@ -1084,11 +1084,24 @@ static bool conv_dma_enabled() {
 
 // tap reuse (TR instantiation): 3x3, stride 1, "same" padding (the folded nearest-x2 upsample included), unsplit K; the 256-row tile is a whole
 // number of image rows of one sample (W = 32 .. 256 a power of two, H * W a multiple of 256)
-static bool conv_tr_ok(const SplitP& p) {
+static bool tr_enabled() {
     static const int mode = getenv("DSD_CONV_TR") ? atoi(getenv("DSD_CONV_TR")) : 1;   // DSD_CONV_TR=0: the plain A-direct kernel (A/B)
-    if (mode <= 0 || p.stamps) return false;
-    return p.ks == 3 && p.stride == 1 && p.pad == 1 && p.OW == p.IWg && p.OH == p.IHg && p.ksplit == 1 && !p.out_nchw &&
-           (p.OW == 32 || p.OW == 64 || p.OW == 128 || p.OW == 256) && p.ohw % (2 * SBM) == 0 && p.M % (2 * SBM) == 0 && p.Cin % SBK == 0;
+    return mode > 0;
+}
+static bool tr_shape_ok(int ks, int stride, int pad, int OW, int IWg, int OH, int IHg, int ksplit, int out_nchw, int ohw, int64_t M, int Cin) {
+    return ks == 3 && stride == 1 && pad == 1 && OW == IWg && OH == IHg && ksplit == 1 && !out_nchw &&
+           (OW == 32 || OW == 64 || OW == 128 || OW == 256) && ohw % (2 * SBM) == 0 && M % (2 * SBM) == 0 && Cin % SBK == 0;
+}
+static bool conv_tr_ok(const SplitP& p) {
+    return tr_enabled() && !p.stamps && tr_shape_ok(p.ks, p.stride, p.pad, p.OW, p.IWg, p.OH, p.IHg, p.ksplit, p.out_nchw, p.ohw, p.M, p.Cin);
+}
+// would conv2d_split(a, nt, ksplit, ad) run the tap-reuse instantiation?  (conv2d_variant: its launches are a kind of their own)
+bool conv2d_split_tr(const ConvArgs& a, int nt, int ksplit, int ad) {
+    if (!(tr_enabled() && !a.stamps && a.precision == PREC_BF16X6 && ad == 2 && nt == 5)) return false;
+    int OH, OW;
+    conv_out_hw(a, &OH, &OW);
+    const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W;
+    return tr_shape_ok(a.ks, a.stride, a.pad_lo >= 0 ? a.pad_lo : a.ks / 2, OW, IWg, OH, IHg, ksplit, a.out_nchw, OH * OW, (int64_t)a.N * OH * OW, a.Cin);
 }
 
 template <int NP, bool F16>

@@ -56,6 +56,7 @@ void conv2d(ConvArgs a, hipStream_t s);
 // conv_split.hip: fp32 operands as sums of bf16 pieces on the bf16 matrix cores
 void split_weights(const float* w, int64_t n, int np, void* planes, hipStream_t s, bool f16 = false, int* ovf = nullptr);
 bool conv2d_split_eligible(const ConvArgs& a);
+bool conv2d_split_tr(const ConvArgs& a, int nt, int ksplit, int ad);   // the tap-reuse instantiation would take it
 void conv2d_split(const ConvArgs& a, int nt, int ksplit, int structure, hipStream_t s);
 double conv2d_flops(const ConvArgs& a);
 size_t conv2d_scratch_bytes(const ConvArgs& a);   // workspace conv2d() can use for these arguments (0 = none)
