@@ -10,7 +10,7 @@ _lib.require_gpu(0)
 shape = [int(v) for v in sys.argv[1:6]] or [16, 256, 256, 320, 320]
 whatifs = [int(v) for v in os.environ.get("DSD_WHATIF", "0").split(",")]
 cap = 1 << 16
-WHAT = {0: "product kernel", 2: "no activation loads", 4: "no weight loads / LDS writes",
+WHAT = {0: "plain A-direct kernel (the product kernel of the layers without tap reuse)", 2: "no activation loads", 4: "no weight loads / LDS writes",
         8: "no barrier", 16: "no weight fragment reads", 31: "bare MFMA stream of this kernel",
         32: "loads issued in bursts of eight (the schedule before r2; correct results)",
         512: "tap reuse: one filter row in LDS serves the three taps (correct results)",
