@@ -107,6 +107,11 @@ class NativeModule(nn.Module):
         check(lib().dsd_set_fuse_gn_stats(self._h, int(on)))
         return self
 
+    def fuse_gn_apply(self, on: bool = True):
+        """GroupNorm + SiLU applied by the consuming 3x3 convolution while it stages its input (default) or by the apply pass."""
+        check(lib().dsd_set_fuse_gn_apply(self._h, int(on)))
+        return self
+
     def graph_stats(self):
         c, l = C.c_int(), C.c_int()
         check(lib().dsd_graph_stats(self._h, C.byref(c), C.byref(l)))

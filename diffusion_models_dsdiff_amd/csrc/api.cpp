@@ -245,6 +245,16 @@ int dsd_set_fuse_gn_stats(dsd_handle* h, int on) {
     DSD_CATCH
 }
 
+int dsd_set_fuse_gn_apply(dsd_handle* h, int on) {
+    DSD_TRY
+    DSD_CHECK(h, "null handle");
+    if (h->fuse_gn_apply != (on != 0)) {
+        h->fuse_gn_apply = on != 0;
+        h->plan.valid = false;
+    }
+    DSD_CATCH
+}
+
 int dsd_set_winograd(dsd_handle* h, int on) {
     DSD_TRY
     DSD_CHECK(h, "null handle");

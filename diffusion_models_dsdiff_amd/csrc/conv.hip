@@ -642,6 +642,19 @@ int conv2d_stats_chunks(const ConvArgs& a) {
     return ohw % rows == 0 ? ohw / rows : 0;
 }
 
+bool conv2d_fuses_gn(const ConvArgs& a) {
+    if (a.Cin % 4 != 0 || a.ks * a.ks * a.Cin < 32 || a.precision != PREC_BF16X6 || a.w_split == nullptr) return false;
+    static const bool off = getenv("DSD_NO_GN_FUSE") != nullptr;   // A/B
+    if (off || conv2d_wino_eligible(a)) return false;
+    int OH, OW;
+    conv_out_hw(a, &OH, &OW);
+    const int tm = cdiv((int64_t)a.N * OH * OW, BM);
+    if (effective_precision(a, tm) != PREC_BF16X6) return false;
+    int nt = pick_nt(a.Cout, tm, PREC_BF16X6), ks = 1, ad = 0;
+    conv2d_split_plan(a, nt, &nt, &ks, &ad, true);
+    return conv2d_split_tr(a, nt, ks, ad);
+}
+
 void conv2d_plan_query(const ConvArgs& a, int* structure, int* nt_out, int* ks_out) {
     int OH, OW;
     conv_out_hw(a, &OH, &OW);
@@ -679,11 +692,16 @@ const char* conv2d_variant(const ConvArgs& a) {
     std::string& n = pool[pr][nt][ad][ks > 1][tr];
     if (n.empty())
         n = std::string(names[pr][nt]) + (ad == 2 ? "" : (ad == 1 ? "/r128" : "/staged")) + (ks > 1 ? "+splitk" : "") + (tr ? "/tr" : "");
+    if (tr && a.gn_scale) {   // the instantiation that also applies GroupNorm + SiLU to its input: a kind (kernel symbol) of its own
+        static const std::string gn = n + "+gn";
+        return gn.c_str();
+    }
     return n.c_str();
 }
 
 void conv2d(ConvArgs a, hipStream_t s) {
     DSD_CHECK(a.ks == 1 || a.ks == 3, "conv2d: kernel size %d unsupported", a.ks);
+    DSD_CHECK(a.gn_scale == nullptr || conv2d_fuses_gn(a), "conv2d: GroupNorm coefficients given, but this problem does not run on the kernel that applies them");
     DSD_CHECK(a.stride == 1 || a.stride == 2, "conv2d: stride %d unsupported", a.stride);
     ConvP p{};
     p.x = a.x; p.w = a.w; p.bias = a.bias; p.emb = a.emb; p.res = a.res; p.y = a.y;

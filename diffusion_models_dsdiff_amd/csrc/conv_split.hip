@@ -141,10 +141,14 @@ static void launch_split(const SplitP& p, int nt, hipStream_t s, int ad) {   // 
         return;
     }
     if (ad == 2 && nt == 5 && NP == 3 && !F16 && conv_tr_ok(p)) {
-        hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 0, true>), grid, dim3(256), 0, s, p);
+        if (p.gn_scale)
+            hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 0, true, true>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 0, true>), grid, dim3(256), 0, s, p);
         check_launch("conv_split_ad2_tr");
         return;
     }
+    if (p.gn_scale) fail("conv2d: GroupNorm coefficients given for a problem the tap-reuse kernel does not take (ask conv2d_fuses_gn first)");
     if (ad == 2 && conv_dma_enabled() && nt == 5 && NP == 3 && !F16) {
         hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, true>), grid, dim3(256), 0, s, p);
         check_launch("conv_split_ad2_dma");
@@ -286,6 +290,9 @@ void conv2d_split(const ConvArgs& a, int nt, int ksplit, int ad, hipStream_t s) 
     p.stats_chunks = 0;
     p.stamps = a.stamps;
     p.diag = a.diag;
+    p.gn_scale = a.gn_scale;
+    p.gn_shift = a.gn_shift;
+    DSD_CHECK((a.gn_scale == nullptr) == (a.gn_shift == nullptr), "conv2d: gn_scale and gn_shift come together");
     if (a.stats) {
         const int rows = ad == 2 ? 2 * SBM : SBM;
         DSD_CHECK(p.ksplit == 1 && !a.out_nchw && p.ohw % rows == 0 && p.ohw / rows == a.stats_chunks && !(ad == 1 && nt >= 4),

@@ -38,6 +38,11 @@ struct ConvArgs {
     // s_memrealtime) at entry, in front of the k-loop, behind it, and after the epilogue
     long long* stamps = nullptr;
     int diag = 0;   // what-if bits (conv_split.hip, DIAG)
+    // GroupNorm + SiLU of the INPUT applied while the filter rows are staged (tap-reuse kernel only: conv2d_fuses_gn()):
+    // x is then the tensor BEFORE the normalisation and gn_scale / gn_shift are gn_finalize's per-(sample, channel)
+    // coefficients [N][Cin]; the separate apply pass over HBM disappears
+    const float* gn_scale = nullptr;
+    const float* gn_shift = nullptr;
 };
 // Output size.  Default padding is ks/2 on every side (the U-Net's convolutions); pad_lo / pad_total describe the VAE's
 // Downsample (ldm/modules/diffusionmodules/model.py:78-83: F.pad (0,1,0,1) then a stride-2 conv with padding 0), i.e. no
@@ -57,6 +62,7 @@ void conv2d(ConvArgs a, hipStream_t s);
 void split_weights(const float* w, int64_t n, int np, void* planes, hipStream_t s, bool f16 = false, int* ovf = nullptr);
 bool conv2d_split_eligible(const ConvArgs& a);
 bool conv2d_split_tr(const ConvArgs& a, int nt, int ksplit, int ad);   // the tap-reuse instantiation would take it
+bool conv2d_fuses_gn(const ConvArgs& a);   // conv2d(a) can apply GroupNorm + SiLU to its input itself (a.gn_scale / a.gn_shift)
 void conv2d_split(const ConvArgs& a, int nt, int ksplit, int structure, hipStream_t s);
 double conv2d_flops(const ConvArgs& a);
 size_t conv2d_scratch_bytes(const ConvArgs& a);   // workspace conv2d() can use for these arguments (0 = none)

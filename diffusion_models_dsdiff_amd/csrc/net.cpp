@@ -667,7 +667,7 @@ struct Builder {
     // of a tensor of its own — the decoder's cat([h, skip]) without the copy of h; the returned Tn is then a view of *dst.
     Tn conv(const std::string& name, const Tn& x, int cout, int ks, int stride = 1, bool ups = false,
             const EmbRef* emb = nullptr, const Tn* res = nullptr, int plane = -1, bool to_out = false, bool bias = true,
-            const Tn* dst = nullptr, bool want_stats = false, int pad_lo = -1, int pad_total = -1) {
+            const Tn* dst = nullptr, bool want_stats = false, int pad_lo = -1, int pad_total = -1, const GnRef* gn = nullptr) {
         ConvArgs a;
         a.N = x.n; a.H = x.h; a.W = x.w; a.Cin = x.c; a.Cout = cout; a.ks = ks; a.stride = stride; a.ups = ups ? 1 : 0;
         a.pad_lo = pad_lo; a.pad_total = pad_total;
@@ -726,6 +726,12 @@ struct Builder {
                 a.w_wino = wi->second;
             }
         }
+        if (gn) {   // the kernel applies GroupNorm + SiLU to x itself (the caller asked can_fuse_gn first)
+            a.gn_scale = a.gn_shift = reinterpret_cast<const float*>(this);   // non-null placeholders for the plan-time queries
+            DSD_CHECK(gn->act == ACT_SILU && conv2d_fuses_gn(a), "conv %s: cannot take the GroupNorm of its input", name.c_str());
+        }
+        const size_t gsc = gn ? gn->scoff : 0, gsh = gn ? gn->shoff : 0;
+        const bool has_gn = gn != nullptr;
         const size_t skb = conv2d_scratch_bytes(a);            // split-K partial tiles of the small-grid layers
         const size_t skoff = skb ? alloc_raw(skb) : 0;
         // GroupNorm statistics of the output from the epilogue, when the kernel this problem gets can emit them
@@ -774,6 +780,10 @@ struct Builder {
                 c.stats = reinterpret_cast<double*>(h->arena + stoff);
                 c.stats_chunks = stchunks;
             }
+            if (has_gn) {
+                c.gn_scale = reinterpret_cast<const float*>(h->arena + gsc);
+                c.gn_shift = reinterpret_cast<const float*>(h->arena + gsh);
+            }
             conv2d(c, s);
         }, skb ? 2 : 1, conv2d_variant(a), conv2d_flops(a),
            4.0 * ((double)x.n * x.h * x.w * x.c + (double)cout * x.c * ks * ks + (double)x.n * OH * OW * cout * (has_res ? 2 : 1)));
@@ -801,7 +811,16 @@ struct Builder {
             }, 1, act == ACT_SILU ? "gn_silu_small" : "gn_small", 0.0, 12.0 * N * HW * C);
             return y;
         }
-        // statistics that came with the tensor (convolution epilogue / concat kernel), else a pass of our own
+        GnRef g = gn_prepare(name, x, act, eps, film);
+        Tn y = gn_apply(g);
+        gn_release(g);
+        return y;
+    }
+
+    // statistics (those that came with the tensor — convolution epilogue / concat kernel — else a pass of our own) + finalize:
+    // the per-(sample, channel) scale / shift of the normalisation stay allocated until gn_release()
+    GnRef gn_prepare(const std::string& name, const Tn& x, int act, float eps = 1e-5f, const EmbRef* film = nullptr) {
+        const int HW = x.hw(), C = x.c, N = x.n;
         const bool have = x.st[0].valid() && x.st[0].c0 == 0 &&
                           (x.st[0].c == C || (x.st[1].valid() && x.st[1].c0 == x.st[0].c && x.st[0].c + x.st[1].c == C));
         const StatRef r0 = x.st[0], r1 = (have && x.st[0].c < C) ? x.st[1] : StatRef{};
@@ -809,12 +828,11 @@ struct Builder {
         const size_t pbytes = have ? 0 : (size_t)N * nchunk * C * 2 * sizeof(double);
         const size_t sbytes = (size_t)N * C * sizeof(float);
         const size_t poff = have ? 0 : alloc_raw(pbytes), scoff = alloc_raw(sbytes), shoff = alloc_raw(sbytes);
-        Tn y = alloc(x.n, x.h, x.w, x.c);
         const float* gamma = W(name + ".weight");
         const float* beta = W(name + ".bias");
         DSD_CHECK(hd->PP(name + ".weight").numel == C, "norm %s: %lld channels, graph expects %d", name.c_str(),
                   (long long)hd->PP(name + ".weight").numel, C);
-        const size_t xoff = x.off, yoff = y.off;
+        const size_t xoff = x.off;
         EmbRef e;
         if (film) e = *film;
         dsd_handle* h = hd;
@@ -837,14 +855,37 @@ struct Builder {
             gn_finalize(s0, s1, N, HW, C, gamma, beta, eps, fp, e.stride,
                         reinterpret_cast<float*>(h->arena + scoff), reinterpret_cast<float*>(h->arena + shoff), s);
         }, 1, "gn_finalize");
+        if (!have) release_raw(poff, pbytes);
+        GnRef g;
+        g.x = x; g.scoff = scoff; g.shoff = shoff; g.sbytes = sbytes; g.act = act;
+        return g;
+    }
+    // the apply pass: y = act(x * scale + shift) as a tensor of its own (one read + one write through HBM)
+    Tn gn_apply(const GnRef& g) {
+        const Tn& x = g.x;
+        const int HW = x.hw(), C = x.c, N = x.n, act = g.act;
+        Tn y = alloc(x.n, x.h, x.w, x.c);
+        const size_t xoff = x.off, yoff = y.off, scoff = g.scoff, shoff = g.shoff;
+        dsd_handle* h = hd;
         op([=](hipStream_t s) {
             affine_act(reinterpret_cast<const float*>(h->arena + xoff), N, HW, C, reinterpret_cast<float*>(h->arena + scoff),
                        reinterpret_cast<float*>(h->arena + shoff), act, reinterpret_cast<float*>(h->arena + yoff), s);
-        }, 1, act == ACT_SILU ? "gn_silu_apply" : "gn_apply", 0.0, 2.0 * tbytes);
-        if (!have) release_raw(poff, pbytes);
-        release_raw(scoff, sbytes);
-        release_raw(shoff, sbytes);
+        }, 1, act == ACT_SILU ? "gn_silu_apply" : "gn_apply", 0.0, 8.0 * N * HW * C);
         return y;
+    }
+    void gn_release(const GnRef& g) {
+        release_raw(g.scoff, g.sbytes);
+        release_raw(g.shoff, g.sbytes);
+    }
+    // would conv(name, x, cout, 3) apply the GroupNorm + SiLU of its input by itself?  (the tap-reuse kernel, bf16x6 only)
+    bool can_fuse_gn(const Tn& x, int cout) {
+        if (!hd->fuse_gn_apply || hd->precision != PREC_BF16X6 || x.c % 32 != 0) return false;
+        ConvArgs a;
+        a.N = x.n; a.H = x.h; a.W = x.w; a.Cin = x.c; a.Cout = cout; a.ks = 3; a.stride = 1;
+        a.precision = PREC_BF16X6;
+        a.w_split = this;   // (non-null: only the shape matters here)
+        if (hd->use_winograd && conv2d_wino_worthwhile(a)) return false;
+        return conv2d_fuses_gn(a);
     }
 
     Tn resample(const Tn& x, bool up) {
@@ -865,29 +906,48 @@ struct Builder {
                  const Tn* dst = nullptr) {
         DSD_CHECK(x.c == cin, "ResBlock %s: input has %d channels, expected %d", p.c_str(), x.c, cin);
         const bool film = hd->PP(pre(p, "emb_layers.1.weight")).shape[0] == 2 * cout;
-        Tn a = gn_act(pre(p, "in_layers.0"), x, ACT_SILU);
+        // GroupNorm + SiLU in front of a 3x3 convolution: the large layers apply it while they stage their input (no apply pass)
         Tn xs = x;
         bool xs_owned = false;
-        if (up || down) {
-            Tn a2 = resample(a, up);
+        Tn h;
+        const bool gn_small_in = hd->fuse_gn_stats && gn_small_ok(x.hw(), x.c);
+        if (!up && !down && !gn_small_in && can_fuse_gn(x, cout)) {
+            GnRef g = gn_prepare(pre(p, "in_layers.0"), x, ACT_SILU);
+            h = conv(pre(p, "in_layers.2"), x, cout, 3, 1, false, film ? nullptr : &emb, nullptr, -1, false, true, nullptr,
+                     /*want_stats=*/true, -1, -1, &g);
+            gn_release(g);
+        } else {
+            Tn a = gn_act(pre(p, "in_layers.0"), x, ACT_SILU);
+            if (up || down) {
+                Tn a2 = resample(a, up);
+                release(a);
+                a = a2;
+                xs = resample(x, up);
+                xs_owned = true;
+            }
+            h = conv(pre(p, "in_layers.2"), a, cout, 3, 1, false, film ? nullptr : &emb, nullptr, -1, false, true, nullptr,
+                     /*want_stats=*/true);   // out_layers.0 normalises exactly this tensor
             release(a);
-            a = a2;
-            xs = resample(x, up);
-            xs_owned = true;
         }
-        Tn h = conv(pre(p, "in_layers.2"), a, cout, 3, 1, false, film ? nullptr : &emb, nullptr, -1, false, true, nullptr,
-                    /*want_stats=*/true);   // out_layers.0 normalises exactly this tensor
-        release(a);
-        Tn a3 = gn_act(pre(p, "out_layers.0"), h, ACT_SILU, 1e-5f, film ? &emb : nullptr);
-        release(h);
         Tn skip = xs;
         bool skip_owned = false;
         if (cin != cout) {
             skip = conv(pre(p, "skip_connection"), xs, cout, 1);
             skip_owned = true;
         }
-        Tn out = conv(pre(p, "out_layers.3"), a3, cout, 3, 1, false, nullptr, &skip, -1, false, true, dst, true);
-        release(a3);
+        Tn out;
+        const bool gn_small_out = hd->fuse_gn_stats && gn_small_ok(h.hw(), h.c);
+        if (!gn_small_out && can_fuse_gn(h, cout)) {
+            GnRef g = gn_prepare(pre(p, "out_layers.0"), h, ACT_SILU, 1e-5f, film ? &emb : nullptr);
+            out = conv(pre(p, "out_layers.3"), h, cout, 3, 1, false, nullptr, &skip, -1, false, true, dst, true, -1, -1, &g);
+            gn_release(g);
+            release(h);
+        } else {
+            Tn a3 = gn_act(pre(p, "out_layers.0"), h, ACT_SILU, 1e-5f, film ? &emb : nullptr);
+            release(h);
+            out = conv(pre(p, "out_layers.3"), a3, cout, 3, 1, false, nullptr, &skip, -1, false, true, dst, true);
+            release(a3);
+        }
         if (skip_owned) release(skip);
         if (xs_owned) release(xs);
         return out;

@@ -40,6 +40,14 @@ struct Tn {
     int hw() const { return h * w; }
 };
 
+// A GroupNorm whose statistics are finalised (per-(sample, channel) scale / shift in the arena) but not yet applied: either
+// the apply pass makes a tensor of it, or the consuming convolution applies it while staging its input (conv2d_fuses_gn).
+struct GnRef {
+    Tn x;
+    size_t scoff = 0, shoff = 0, sbytes = 0;
+    int act = 0;
+};
+
 struct ArenaPlanner {
     struct Blk { size_t off, size; };
     std::vector<Blk> free_list;  // sorted by offset
@@ -131,6 +139,7 @@ struct dsd_handle {
     int use_graph = 0;
     int use_winograd = 0;    // bf16x6 only, opt-in: 3x3 stride-1 convolutions as F(2,3) along the width (conv_wino.hip)
     int fuse_gn_stats = 1;   // GroupNorm statistics from the producing kernel's epilogue (0: always the standalone pass)
+    int fuse_gn_apply = 1;   // GroupNorm + SiLU applied by the consuming 3x3 convolution while it stages its input (0: apply pass)
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;
     dsd::GraphKey gkey;

@@ -106,6 +106,13 @@ int dsd_set_share_zero_streams(dsd_handle* h, int on);
  * in the epilogue of the kernel that writes the tensor and the separate statistics pass over HBM disappears
  * (openaimodel.py:264-284: "fused GroupNorm" of the north star).  0 = always run the standalone pass (A/B, tests). */
 int dsd_set_fuse_gn_stats(dsd_handle* h, int on);
+/* GroupNorm + SiLU in front of a 3x3 convolution (ResBlock in_layers / out_layers, openaimodel.py:264-284), ON by default in
+ * the bf16x6 mode: the large layers — those the tap-reuse kernel takes — apply the normalisation while they stage their input
+ * rows into LDS, so the apply pass (one read + one write of the tensor through HBM per GroupNorm) disappears.  An element is
+ * then activated once per filter row and column tile (6x on a 320-channel layer) in VALU slots of the convolution, with the
+ * hardware exp2 / reciprocal (~1 ulp each) instead of expf and an IEEE division: the outputs agree with the apply-pass route
+ * to fp32 rounding (measured 1e-7 relative on the network output), not bit for bit.  0 = always the separate pass. */
+int dsd_set_fuse_gn_apply(dsd_handle* h, int on);
 /* bf16x6 mode only, OFF by default: 3x3 stride-1 convolutions whose grid fills the chip at least twice (>= 512 workgroups),
  * with an output width that is a power of two <= 256, Cin % 32 == 0 and Cout = 0 or 64 (mod 128), run as Winograd F(2,3)
  * ALONG THE WIDTH — 4 instead of 6 products per pair of outputs and filter row, i.e. 1.5x fewer MFMAs.  The input transform

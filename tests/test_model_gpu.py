@@ -541,3 +541,31 @@ def test_full_size_full_length_chain_default_vs_exact_fp32(full_model):
     assert err < 1e-4
     assert torch.equal(run_device_loop(m, sched, xT, cond, seed=77, first_step=0, n_steps=25),
                        run_device_loop(m, sched, xT, cond, seed=77, first_step=0, n_steps=25))
+
+
+def test_gn_apply_inside_the_consuming_convolution(full_model):
+    """GroupNorm + SiLU applied by the consuming 3x3 convolution while it stages its input rows (dsd_set_fuse_gn_apply, on by
+    default in bf16x6 for the layers the tap-reuse kernel takes) against the separate apply pass: the same affine + SiLU on
+    the same values, the fused one with the hardware exp2 / reciprocal (about 1 ulp each) where the pass uses expf and an IEEE
+    division — the outputs agree to fp32 rounding, the apply launches of the large layers are gone, and the result holds the
+    full-size tolerance against the oracle either way (test_full_size_vs_oracle runs with the default, on)."""
+    m, cfg, sd = full_model
+    m.set_precision("bf16x6")
+    x, t = randn((2, 2, 256, 256), 16).cuda(), torch.tensor([17, 905]).cuda()
+    m.fuse_gn_apply(False)
+    y0 = m._run(x, t, want_feats=False)[0]
+    n0 = m.plan_info()["launches"]
+    m.fuse_gn_apply(True)
+    y1 = m._run(x, t, want_feats=False)[0]
+    n1 = m.plan_info()["launches"]
+    print(f"fuse_gn_apply: {n0} -> {n1} launches per forward, max |diff| {float((y1 - y0).abs().max()):.3e}")
+    assert rel_l2(y1, y0) < 5e-6      # (the network amplifies ulp-level differences to the level of its own fp32 re-ordering noise)
+    assert n1 <= n0 - 40, (n0, n1)
+    yo2 = O.unet_forward(cfg, sd, x[:1].cpu(), t[:1].cpu())[0]
+    e1, e0 = rel_l2(y1[:1], yo2), rel_l2(y0[:1], yo2)
+    print(f"vs the oracle at 256x256: fused {e1:.3e}, apply pass {e0:.3e}")
+    assert e1 < 1e-5 and e0 < 1e-5
+    # small maps (64 x 64 input: nothing for the tap-reuse kernel below 32 x 32) keep working through the mixed plan
+    xs, ts = randn((1, 2, 64, 64), 5), torch.tensor([731])
+    yo = O.unet_forward(cfg, sd, xs, ts)[0]
+    assert rel_l2(m._run(xs.cuda(), ts.cuda(), want_feats=False)[0], yo) < 1e-5
