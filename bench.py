@@ -175,8 +175,10 @@ def kernel_symbol(kind):
     np_, f16 = {"bf16x6": ("3", "false"), "bf16x3": ("2", "false"), "f16x3": ("2", "true")}[mode]
     if st == "/staged":
         return f"conv_split_kernel<{nt},{np_},{f16}>"
-    # (the product instantiations carry three more template arguments: LDS-DMA weights off, diagnostics off, tap reuse on / off)
-    return f"conv_split_ad_kernel<{nt},{np_},{f16},{'1' if st == '/r128' else '2'},false,0,{'true' if kind.endswith('/tr') else 'false'}>"
+    # (the product instantiations carry four more template arguments: LDS-DMA weights off, diagnostics off, tap reuse and
+    # fused GroupNorm apply on / off)
+    tr, gn = ("/tr" in kind), kind.endswith("+gn")
+    return f"conv_split_ad_kernel<{nt},{np_},{f16},{'1' if st == '/r128' else '2'},false,0,{'true' if tr else 'false'},{'true' if gn else 'false'}>"
 
 
 def latest_pmc(precision="bf16x6"):

@@ -61,7 +61,7 @@ for k in sorted(fe, key=lambda k: -sum(du.get(k, [0]))):
                                 "active": round(s.get("SQ_ACTIVE_INST_ANY", 0) / s["SQ_WAVE_CYCLES"], 3)}
     if s.get("SQ_LDS_IDX_ACTIVE"):
         e["lds_bank_conflict_frac"] = round(s.get("SQ_LDS_BANK_CONFLICT", 0) / s["SQ_LDS_IDX_ACTIVE"], 4)
-    res[k.replace("void ", "")[:60]] = e
+    res[k.replace("void ", "")[:110]] = e   # (long enough for every template argument of the convolution kernels)
 res["_meta"] = meta
 json.dump(res, open(out + ".json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])

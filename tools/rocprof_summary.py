@@ -13,10 +13,10 @@ rows = c.execute("select name, count(*), sum(duration), avg(duration), min(durat
                  "from kernels group by name order by sum(duration) desc").fetchall()
 tot = sum(r[2] for r in rows)
 res = []
-lines = [f"{'kernel':<70} {'calls':>7} {'total_ms':>12} {'avg_us':>12} {'min_us':>10} {'max_us':>12} {'pct':>7}"]
+lines = [f"{'kernel':<96} {'calls':>7} {'total_ms':>12} {'avg_us':>12} {'min_us':>10} {'max_us':>12} {'pct':>7}"]
 for name, n, s, a, mn, mx in rows:
-    short = name if len(name) <= 70 else name[:67] + "..."
-    lines.append(f"{short:<70} {n:>7} {s / 1e6:>12.3f} {a / 1e3:>12.2f} {mn / 1e3:>10.2f} {mx / 1e3:>12.2f} {100 * s / tot:>7.2f}")
+    short = name if len(name) <= 96 else name[:93] + "..."
+    lines.append(f"{short:<96} {n:>7} {s / 1e6:>12.3f} {a / 1e3:>12.2f} {mn / 1e3:>10.2f} {mx / 1e3:>12.2f} {100 * s / tot:>7.2f}")
     res.append({"kernel": name, "calls": n, "total_ms": s / 1e6, "avg_us": a / 1e3, "min_us": mn / 1e3, "max_us": mx / 1e3,
                 "pct": 100 * s / tot})
 try:
@@ -24,7 +24,7 @@ try:
     lines.append("")
     lines.append("registers / LDS per kernel (arch_vgpr, accum_vgpr, sgpr, lds_bytes):")
     for v, a, s, l, n in meta:
-        lines.append(f"  {n[:80]:<80} {v} {a} {s} {l}")
+        lines.append(f"  {n[:96]:<96} {v} {a} {s} {l}")
 except Exception as e:  # noqa
     pass
 open(out + ".txt", "w").write("\n".join(lines) + "\n")
