@@ -266,3 +266,30 @@ def test_wrapped_model_hands_the_original_timesteps_to_the_network():
         else:
             assert seen["t"].dtype == torch.int64 and np.array_equal(seen["t"].numpy(), tmap[idx.numpy()])
         assert np.array_equal(d._model_timestep_values()[idx.numpy()], seen["t"].numpy().astype(np.float32))
+
+
+def test_bench_kernel_symbols_match_the_committed_profiles():
+    """bench.py maps a plan kind to the kernel symbol rocprofv3 reports (roofline.traffic comes from the PMC summary of that
+    symbol): every convolution kind of the committed bench line must be found in the committed summaries, and the bench
+    line's dominant kernel must have carried its traffic figure."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    line = json.load(open(os.path.join(root, "profiles", "r02_bench_1gpu.json")))
+    pmc = json.load(open(os.path.join(root, "profiles", "r02_pmc.json")))
+    stats = json.load(open(os.path.join(root, "profiles", "r02_kernel_stats.json")))
+    names = [k.replace(" ", "") for k in pmc if k != "_meta"]
+    traced = [e["kernel"].replace(" ", "") for e in stats]
+    kinds = [k for k in line["kernels"] if k.startswith("conv_bf16x6")]
+    assert len(kinds) >= 5
+    for k in kinds:
+        sym = bench.kernel_symbol(k)
+        assert sym and any(sym in n for n in names), (k, sym)
+        assert any(sym in n for n in traced), (k, sym)
+    r = line["roofline"]
+    assert r["traffic"] and r["traffic_source"]["file"] == "profiles/r02_pmc.json"
+    assert bench.kernel_symbol(r["kernel"]) in r["traffic_source"]["kernel"].replace(" ", "")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.3 < r["frac"] < 1.0
