@@ -184,6 +184,29 @@ class NativeModule(nn.Module):
         if torch.cuda.is_available():
             torch.cuda.current_stream().synchronize()
 
+    # ---- introspection used by bench.py / tests
+    def plan_info(self):
+        L = lib()
+        return {"workspace_bytes": int(L.dsd_workspace_bytes(self._h)), "launches": int(L.dsd_plan_launches(self._h)),
+                "flops": float(L.dsd_plan_flops(self._h)), "device_bytes": int(L.dsd_device_bytes(self._h))}
+
+    def profile(self, on: bool):
+        """Per-kernel hipEvent timing of every op of the plan (dsd_profile_enable)."""
+        check(lib().dsd_profile_enable(self._h, int(on)))
+
+    def profile_report(self):
+        """{kernel: {ms, flops, bytes, calls}} summed over the forwards run since profile(True); 'runs' = #forwards."""
+        L = lib()
+        out, runs = {}, 0
+        kind, ms, fl, by = C.c_char_p(), C.c_double(), C.c_double(), C.c_double()
+        calls, r = C.c_int64(), C.c_int()
+        for i in range(L.dsd_profile_count(self._h)):
+            check(L.dsd_profile_get(self._h, i, C.byref(kind), C.byref(ms), C.byref(fl), C.byref(by), C.byref(calls),
+                                    C.byref(r)))
+            out[kind.value.decode()] = {"ms": ms.value, "flops": fl.value, "bytes": by.value, "calls": calls.value}
+            runs = r.value
+        return out, runs
+
     def __del__(self):
         try:
             if getattr(self, "_h", None) and self._h.value:
@@ -325,29 +348,6 @@ class DSUnetModel(NativeModule):
                 feats[k] = feats_t[i:i + n]
                 i += n
         return out, feats
-
-    # ---- introspection used by bench.py / tests
-    def plan_info(self):
-        L = lib()
-        return {"workspace_bytes": int(L.dsd_workspace_bytes(self._h)), "launches": int(L.dsd_plan_launches(self._h)),
-                "flops": float(L.dsd_plan_flops(self._h)), "device_bytes": int(L.dsd_device_bytes(self._h))}
-
-    def profile(self, on: bool):
-        """Per-kernel hipEvent timing of every op of the plan (dsd_profile_enable)."""
-        check(lib().dsd_profile_enable(self._h, int(on)))
-
-    def profile_report(self):
-        """{kernel: {ms, flops, bytes, calls}} summed over the forwards run since profile(True); 'runs' = #forwards."""
-        L = lib()
-        out, runs = {}, 0
-        kind, ms, fl, by = C.c_char_p(), C.c_double(), C.c_double(), C.c_double()
-        calls, r = C.c_int64(), C.c_int()
-        for i in range(L.dsd_profile_count(self._h)):
-            check(L.dsd_profile_get(self._h, i, C.byref(kind), C.byref(ms), C.byref(fl), C.byref(by), C.byref(calls),
-                                    C.byref(r)))
-            out[kind.value.decode()] = {"ms": ms.value, "flops": fl.value, "bytes": by.value, "calls": calls.value}
-            runs = r.value
-        return out, runs
 
     def convert_to_fp16(self):
         raise NotImplementedError("the hot path is fp32 end-to-end (SURVEY.md 9, quirk 8)")

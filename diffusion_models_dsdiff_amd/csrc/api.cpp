@@ -180,7 +180,10 @@ int dsd_set_timestep_freqs(dsd_handle* h, const float* freqs_host, int n) {
 int dsd_set_precision(dsd_handle* h, int precision) {
     DSD_TRY
     DSD_CHECK(h, "null handle");
-    DSD_CHECK(precision >= PREC_F32 && precision <= PREC_F16X3, "unknown precision %d", precision);
+    DSD_CHECK(precision >= PREC_F32 && precision <= PREC_BF16, "unknown precision %d", precision);
+    DSD_CHECK(precision <= PREC_F16X3 || (h->is_block && h->block_kind == DSD_BLOCK_DIT),
+              "DSD_PREC_F16 / DSD_PREC_BF16 (single-product autocast arithmetic) exist for DSD_BLOCK_DIT handles only: the other "
+              "networks are checked against the fp32 CPU path at 1e-4 and keep fp32-grade products");
     if (h->precision != precision) {
         set_device(h->device);
         h->precision = precision;
@@ -730,6 +733,48 @@ int dsd_op_qkv_attention(const float* qkv, int N, int T, int C, int heads, int n
     a.out = out;
     a.split = split != 0;
     attention(a, (hipStream_t)stream);
+    DSD_CATCH
+}
+
+int dsd_op_gemm_half(const float* x, const float* w, const float* bias, int M, int N, int K, int bf16, int epi, const float* gate,
+                     int T, float* y, void* stream) {
+    DSD_TRY
+    DSD_CHECK(x && w && y && epi >= 0 && epi <= 2 && (epi != 2 || (gate && T >= 1)), "bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    Tmp x16((size_t)M * K * 2), w16((size_t)N * K * 2), y16((size_t)M * N * 2);
+    cast16(x, (int64_t)M * K, x16.p, bf16, s);
+    cast16(w, (int64_t)N * K, w16.p, bf16, s);
+    Gemm16Args a;
+    a.x = x16.p; a.ldx = K; a.w = w16.p; a.bias = bias; a.M = M; a.N = N; a.K = K; a.bf16 = bf16; a.epi = epi;
+    a.y16 = y16.p; a.ldy = N;
+    if (epi == EPI16_GATED) {
+        a.x32 = y; a.ldx32 = N; a.gate = gate; a.gate_stride = N; a.T = T;
+    }
+    gemm16(a, s);
+    if (epi != EPI16_GATED) uncast16(y16.p, (int64_t)M * N, y, bf16, s);
+    DSD_CATCH
+}
+
+int dsd_op_attention_half(const float* qkv, int N, int T, int C, int heads, int bf16, float thr, float* out, void* stream) {
+    DSD_TRY
+    DSD_CHECK(qkv && out && heads > 0 && C % heads == 0, "C=%d not divisible by heads=%d", C, heads);
+    hipStream_t s = (hipStream_t)stream;
+    const int d = C / heads;
+    Tmp q16((size_t)N * T * 3 * C * 2), o16((size_t)N * T * C * 2);
+    cast16(qkv, (int64_t)N * T * 3 * C, q16.p, bf16, s);
+    Attn16Args a;
+    a.N = N; a.Tq = a.Tk = T; a.heads = heads; a.d = d;
+    a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
+    a.q_hs = a.k_hs = a.v_hs = d;
+    a.q = q16.p;
+    a.k = (const char*)q16.p + (size_t)C * 2;
+    a.v = (const char*)q16.p + (size_t)2 * C * 2;
+    a.scale_q = 1.4426950408889634f / std::sqrt((float)d);   // scores as base-2 logits
+    a.thr = thr;
+    a.bf16 = bf16;
+    a.out = o16.p;
+    attention16(a, s);
+    uncast16(o16.p, (int64_t)N * T * C, out, bf16, s);
     DSD_CATCH
 }
 

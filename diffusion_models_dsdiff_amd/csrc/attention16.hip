@@ -1,0 +1,267 @@
+// attention16.hip — flash attention on 16-bit operands (fp16 or bf16), fp32 accumulation and softmax statistics:
+// the attention of the transformer backbone in the arithmetic BASELINE configs[4] names (timm Attention under fp16 autocast,
+// UNet_DS_Diff/DiT_models.py:101-122: q k^T and attn v are half-precision matmuls, the softmax is fp32).
+//
+// One workgroup = (sample, head, 128 queries), 4 waves x 32 queries, 64 keys per LDS stage.
+//   * S^T = K Q^T (v_mfma_f32_32x32x16): the lane owns ONE query column, so the row maximum / sum are in-lane plus one
+//     exchange with the other lane half, and exp2(S^T) is already the B operand of O^T = V^T P^T: P never leaves registers.
+//     The accumulator gives a lane the keys 4h + (r & 3) + 8 (r >> 2) of a 32-key sub-tile; k-step s of the second product
+//     takes registers 8s .. 8s+7 as they are and the V^T fragment is fetched in the matching key order.
+//   * K is staged k-step-major: plane s holds [key][d = 16 s .. 16 s + 15] (32 B per key, 16-byte halves XOR-swizzled by
+//     (key >> 3) & 1): the A-operand read (lane = key, 16 B) is a conflict-free ds_read_b128 for every head dim.
+//   * V is staged d-tile-major: plane t holds [key][d = 32 t .. 32 t + 31] (64 B per key); the A operand of the second
+//     product needs V TRANSPOSED (lane = d, 8 keys) and comes from ds_read_b64_tr_b16, the hardware transpose read: four
+//     consecutive keys x 16 d per 16-lane group, 256 contiguous bytes per 32 lanes — conflict-free, and no 2-byte scatter
+//     stores (what made the split kernel's V^T staging conflict on 48 % of its LDS cycles).
+//   * Softmax in base 2: q arrives pre-multiplied by hd^-1/2 log2(e) (the qkv GEMM's epilogue does it in fp32 before the one
+//     rounding to 16 bits), the NEGATED running maximum is the C operand of the first S^T MFMA, so the score tile comes out
+//     as s - m and p = exp2(that) costs one v_exp_f32.  The maximum is only moved when a score exceeds it by more than 2^THR
+//     (a wave-uniform branch): O, l and the pending tile are then rescaled together, before any of the tile is exponentiated
+//     (cdna_hip_programming.md T13's safe order).  p <= 2^8 in the 16-bit P, sums in fp32.
+// Head dims: multiples of 8 up to 128 (padding chunks are zeroed once); keys beyond Tk are masked in the last tile.
+#include "kernels.h"
+
+namespace dsd {
+
+namespace a16 {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct AF;
+template <>
+struct AF<_Float16> {
+    using v8 = f16x8;
+    using v4 = f16x4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct AF<__bf16> {
+    using v8 = bf16x8;
+    using v4 = bf16x4;
+    static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+struct A16P {
+    const void *q, *k, *v;
+    void* out;
+    int ldq, ldk, ldv, ldo, q_hs, k_hs, v_hs;
+    int N, Tq, Tk, heads, d;
+    float scale_q;   // applied to q in fp32 before it is rounded back (1 = q arrives pre-scaled)
+    float thr;       // rescale threshold in log2 units
+};
+
+template <typename T16, int NKS>
+__global__ __launch_bounds__(256, 2) void attention16_kernel(A16P a) {
+    using F = AF<T16>;
+    constexpr int KEYS = 64;
+    constexpr int DT = (NKS + 1) / 2;        // 32-wide d tiles of O^T
+    constexpr int CH = 2 * NKS;              // 16-byte chunk slots per key row (K side)
+    constexpr int KPL = KEYS * 32 + 32;      // bytes per K plane (+32: the planes of one key row land on different banks)
+    constexpr int VPL = KEYS * 64 + 64;      // bytes per V plane
+    constexpr int NLD = (KEYS * CH + 255) / 256;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NKS * KPL + DT * VPL];
+    unsigned char* Kl = lds;
+    unsigned char* Vl = lds + NKS * KPL;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, half = lane >> 5;
+    const int n = blockIdx.z, head = blockIdx.y;
+    const int q = blockIdx.x * 128 + wave * 32 + lrow;
+    const bool q_ok = q < a.Tq;
+    const int hch = a.d >> 3;   // valid 16-byte chunks per row
+
+    // zero the whole stage once: padding chunks (d >= head dim) are never written again
+    for (int i = tid * 16; i < NKS * KPL + DT * VPL; i += 256 * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0u, 0u, 0u, 0u};
+
+    // Q^T fragments (B operand of S^T = K Q^T): this lane's query, k-step s covers d = 16 s + 8 half .. + 8
+    typename F::v8 qf[NKS];
+    {
+        const T16* qp = reinterpret_cast<const T16*>(a.q) + ((int64_t)n * a.Tq + (q_ok ? q : 0)) * a.ldq + (int64_t)head * a.q_hs;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const int c = 2 * s + half;
+            typename F::v8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (T16)0.f;
+            if (q_ok && c < hch) t = *reinterpret_cast<const typename F::v8*>(qp + c * 8);
+            if (a.scale_q != 1.f) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = (T16)((float)t[e] * a.scale_q);
+            }
+            qf[s] = t;
+        }
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    f32x16 negm;   // -m in every register: the C operand of the first S^T MFMA
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;   // l_run: this lane's 16 keys of every sub-tile only (the halves are added at the end)
+
+    const T16* kbase = reinterpret_cast<const T16*>(a.k) + (int64_t)n * a.Tk * a.ldk + (int64_t)head * a.k_hs;
+    const T16* vbase = reinterpret_cast<const T16*>(a.v) + (int64_t)n * a.Tk * a.ldv + (int64_t)head * a.v_hs;
+    u32x4 kreg[NLD], vreg[NLD];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * 256;
+            const int kr = i / CH, c = i - kr * CH;
+            const int key = k0 + kr;
+            u32x4 kv = u32x4{0u, 0u, 0u, 0u}, vv = kv;
+            if (kr < KEYS && key < a.Tk && c < hch) {
+                kv = *reinterpret_cast<const u32x4*>(kbase + (int64_t)key * a.ldk + c * 8);
+                vv = *reinterpret_cast<const u32x4*>(vbase + (int64_t)key * a.ldv + c * 8);
+            }
+            kreg[j] = kv;
+            vreg[j] = vv;
+        }
+    };
+    // fragment read offsets
+    const int kofs = (lrow * 32 + half * 16) ^ (((lrow >> 3) & 1) << 4);                      // + s * KPL + sub * 1024
+    const int g = lane >> 4, li = lane & 15;
+    const int vofs = (4 * half + (li >> 2)) * 64 + (16 * (g & 1) + 4 * (li & 3)) * 2;         // + t * VPL + sub * 2048 + s2 * 1024 + j * 512
+
+    fetch(0);
+    bool first = true;
+    for (int k0 = 0; k0 < a.Tk; k0 += KEYS) {
+        __syncthreads();   // every wave is done with the previous tile (and, the first time, the zero fill has landed)
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int i = tid + j * 256;
+            const int kr = i / CH, c = i - kr * CH;
+            if (kr < KEYS && c < hch) {
+                *reinterpret_cast<u32x4*>(Kl + (c >> 1) * KPL + ((kr * 32 + (c & 1) * 16) ^ (((kr >> 3) & 1) << 4))) = kreg[j];
+                *reinterpret_cast<u32x4*>(Vl + (c >> 2) * VPL + kr * 64 + (c & 3) * 16) = vreg[j];
+            }
+        }
+        __syncthreads();
+        if (k0 + KEYS < a.Tk) fetch(k0 + KEYS);
+#pragma unroll
+        for (int sub = 0; sub < KEYS / 32; ++sub) {
+            if (k0 + sub * 32 >= a.Tk) break;
+            // S^T[key][q] - m = sum_d K[key][d] Q[q][d] + (-m)
+            f32x16 sacc = F::mfma(*reinterpret_cast<const typename F::v8*>(Kl + sub * 1024 + kofs), qf[0], negm);
+#pragma unroll
+            for (int s = 1; s < NKS; ++s)
+                sacc = F::mfma(*reinterpret_cast<const typename F::v8*>(Kl + s * KPL + sub * 1024 + kofs), qf[s], sacc);
+            if (k0 + sub * 32 + 32 > a.Tk) {   // last, partial sub-tile: keys beyond Tk take no part
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    sacc[r] = key < a.Tk ? sacc[r] : -INFINITY;
+                }
+            }
+            float tmax = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
+#pragma unroll
+            for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[r]), sacc[r + 1]);
+            tmax = fmaxf(tmax, sacc[15]);
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+            // the maximum moves only when some query of the wave saw a score more than 2^thr above it (always on the first tile)
+            const bool need = first || !(tmax <= a.thr);
+            if (__any(need)) {
+                const float delta = need ? tmax : 0.f;          // first tile: may be negative — m becomes the tile's maximum
+                const float corr = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                for (int t = 0; t < DT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[t][r] *= corr;
+                l_run *= corr;
+                m_run += delta;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    negm[r] = -m_run;
+                    sacc[r] -= delta;
+                }
+                first = false;
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sacc[r] = __builtin_amdgcn_exp2f(sacc[r]);
+                psum += sacc[r];
+            }
+            l_run += psum;
+            typename F::v8 pf[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[s2][e] = (T16)sacc[8 * s2 + e];
+            // O^T[d][q] += sum_key V[key][d] P[key][q]; element j of k-step s2 is key 16 s2 + 8 (j >> 2) + 4 half + (j & 3)
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const unsigned char* vp = Vl + t * VPL + sub * 2048 + s2 * 1024 + vofs;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vp + 512));
+                    const typename F::v8 vf = __builtin_bit_cast(typename F::v8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    o[t] = F::mfma(vf, pf[s2], o[t]);
+                }
+            }
+        }
+    }
+    if (!q_ok) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    T16* op = reinterpret_cast<T16*>(a.out) + ((int64_t)n * a.Tq + q) * a.ldo + (int64_t)head * a.d;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int d = t * 32 + 8 * r4 + 4 * half;
+            if (d < a.d) {   // head dim % 8 == 0 and d % 4 == 0: the four values are valid together
+                typename F::v4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (T16)(o[t][4 * r4 + e] * inv);
+                *reinterpret_cast<typename F::v4*>(op + d) = h;
+            }
+        }
+}
+
+template <typename T16>
+void launch_attn16(const A16P& p, int nks, hipStream_t s) {
+    const dim3 grid(cdiv(p.Tq, 128), p.heads, p.N), block(256);
+    switch (nks) {
+        case 1: hipLaunchKernelGGL((attention16_kernel<T16, 1>), grid, block, 0, s, p); break;
+        case 2: hipLaunchKernelGGL((attention16_kernel<T16, 2>), grid, block, 0, s, p); break;
+        case 3: hipLaunchKernelGGL((attention16_kernel<T16, 3>), grid, block, 0, s, p); break;
+        case 4: hipLaunchKernelGGL((attention16_kernel<T16, 4>), grid, block, 0, s, p); break;
+        case 5: hipLaunchKernelGGL((attention16_kernel<T16, 5>), grid, block, 0, s, p); break;
+        case 6: hipLaunchKernelGGL((attention16_kernel<T16, 6>), grid, block, 0, s, p); break;
+        case 7: hipLaunchKernelGGL((attention16_kernel<T16, 7>), grid, block, 0, s, p); break;
+        default: hipLaunchKernelGGL((attention16_kernel<T16, 8>), grid, block, 0, s, p); break;
+    }
+}
+
+}  // namespace a16
+using namespace a16;
+
+bool attention16_shape_ok(int d) { return d >= 8 && d <= 128 && d % 8 == 0; }
+
+void attention16(const Attn16Args& a, hipStream_t s) {
+    DSD_CHECK(attention16_shape_ok(a.d), "attention16: head dim %d unsupported (multiple of 8, <= 128)", a.d);
+    DSD_CHECK(a.Tk >= 1 && a.Tq >= 1, "attention16: empty sequence");
+    DSD_CHECK(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.q_hs % 8 == 0 && a.k_hs % 8 == 0 && a.v_hs % 8 == 0 && a.ldo % 4 == 0,
+              "attention16: rows must be 16-byte aligned");
+    A16P p{};
+    p.q = a.q; p.k = a.k; p.v = a.v; p.out = a.out;
+    p.ldq = a.ldq; p.ldk = a.ldk; p.ldv = a.ldv; p.ldo = a.ldo; p.q_hs = a.q_hs; p.k_hs = a.k_hs; p.v_hs = a.v_hs;
+    p.N = a.N; p.Tq = a.Tq; p.Tk = a.Tk; p.heads = a.heads; p.d = a.d;
+    p.scale_q = a.scale_q;
+    p.thr = a.thr >= 0.f ? a.thr : 8.f;
+    const int nks = cdiv(a.d, 16);
+    if (a.bf16) launch_attn16<__bf16>(p, nks, s); else launch_attn16<_Float16>(p, nks, s);
+    check_launch("attention16");
+}
+
+}  // namespace dsd

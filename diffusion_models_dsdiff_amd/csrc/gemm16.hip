@@ -1,0 +1,359 @@
+// gemm16.hip — single-product half-precision GEMM for the transformer backbone (DSD_PREC_F16 / DSD_PREC_BF16).
+//
+// BASELINE configs[4] names the arithmetic of the reference's DiT (UNet_DS_Diff/DiT_models.py:101-122 under fp16 autocast):
+// every nn.Linear takes fp16 operands and accumulates in fp32.  This file is that arithmetic on the gfx950 matrix cores:
+//     Y[m][n] = sum_k X[m][k] W[n][k] + bias[n]        X, W 16-bit (fp16 or bf16), fp32 accumulation,
+// ONE v_mfma_f32_16x16x32_{f16,bf16} per 16x16x32 block of products (the split modes of conv_split.hip issue 3 or 6).
+//
+// Tile 256 (n) x 256 (m) x 64 (k), 512 threads: 8 waves as 2 (n) x 4 (m), a wave owns 128 n x 64 m = 8 x 4 accumulator
+// tiles.  The product is computed TRANSPOSED (MFMA A operand = W rows, B operand = X rows), so a lane ends up with FOUR
+// CONSECUTIVE n of one row m: the epilogue stores 8 bytes (16-bit output) or a float4 read-modify-write (gated residual) per
+// lane and tile instead of 2-byte scatters.
+// Operands reach LDS by LDS-DMA (global_load_lds_dwordx4, 16 B per lane, no VGPR round trip), two 64 KB stages; a DMA piece
+// is lane-linear in LDS, so the bank swizzle sits on the SOURCE address (cdna_hip_programming.md rule 21): tile rows are
+// 128 B (64 k), 16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7), and the fragment reads (ds_read_b128, lane =
+// row, 8 consecutive k) apply the same XOR — conflict-free for the 16x16x32 operand pattern (checked lane group by lane
+// group against MI355X_MICROARCH.md §LDS).  Rows beyond M / N and chunks beyond K are fetched from a 16-byte zero buffer.
+// Loop: stage tile t+1, multiply tile t, one barrier (+ vmcnt(0)) per k-tile.
+//
+// Fused epilogues (what DiTBlock.forward does around each Linear):
+//   EPI_STORE   y16 = round16(acc + bias)             columns < qcols first multiplied by qscale (the attention's q scale)
+//   EPI_GELU    y16 = round16(gelu_tanh(round16(acc + bias)))                                   (Mlp: fc1 -> GELU)
+//   EPI_GATED   x32[m][n] += gate[m / T][n] * round16(acc + bias)                               (x + gate * f(...), fp32 stream)
+#include "kernels.h"
+
+namespace dsd {
+
+namespace g16 {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
+constexpr int GBM = 256, GBN = 256, GBK = 64;
+constexpr int G_TILE_BYTES = GBN * GBK * 2;   // 32 KB per operand and stage
+
+template <typename T>
+struct Frag;
+template <>
+struct Frag<_Float16> {
+    using v8 = f16x8;
+    using v4 = f16x4;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
+template <>
+struct Frag<__bf16> {
+    using v8 = bf16x8;
+    using v4 = bf16x4;
+    static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+
+// F.gelu(approximate="tanh") = 0.5 v (1 + tanh(u)), u = sqrt(2/pi) (v + 0.044715 v^3); 0.5 (1 + tanh u) = 1 / (1 + exp(-2u)):
+// one v_exp_f32 and one v_rcp_f32 (the result is rounded to 16 bits right after)
+__device__ __forceinline__ float gelu_tanh_f(float v) {
+    const float u2 = -2.f * 0.7978845608028654f * 1.4426950408889634f * (v + 0.044715f * v * v * v);   // -2u log2(e)
+    return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u2));
+}
+
+struct G16P {
+    const void* x;      // [M][ldx] 16-bit
+    const void* w;      // [N][K] 16-bit
+    const float* bias;  // [N] or null
+    void* y16;          // [M][ldy] 16-bit (EPI_STORE / EPI_GELU)
+    float* x32;         // [M][ldx32] fp32 (EPI_GATED)
+    const float* gate;  // [M / T][gate_stride]
+    int M, N, K, ldx, ldy, ldx32, gate_stride, T, qcols;
+    float qscale;
+    int tiles_m, tiles_n;
+};
+
+template <typename T16, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
+    using F = Frag<T16>;
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * G_TILE_BYTES];   // [stage][W tile | X tile]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave >> 2, wm = wave & 3;
+
+    // XCD-aware tile order: workgroups b and b + 8 share an XCD (and its L2); give each XCD a contiguous run of tiles, the n
+    // tiles of one m tile next to each other, so the X rows of an m tile are fetched from HBM once per XCD
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    const int bm0 = tile_m * GBM, bn0 = tile_n * GBN;
+
+    // ---- staging: per k-tile 4 + 4 LDS-DMA pieces per thread.  Piece j of wave w covers tile rows 64 j + 8 w .. + 8; lane ->
+    // row + (lane >> 3), physical chunk lane & 7, logical chunk (lane & 7) ^ ((row >> 1) & 7)
+    const int srow = wave * 8 + (lane >> 3);                       // + 64 j
+    const int schunk = (lane & 7) ^ ((srow >> 1) & 7);             // ((64 j + srow) >> 1) & 7 == (srow >> 1) & 7
+    const T16* zero = reinterpret_cast<const T16*>(g_zero16);
+    const T16* wsrc[4];
+    const T16* xsrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = bn0 + j * 64 + srow, m = bm0 + j * 64 + srow;
+        wsrc[j] = n < p.N ? reinterpret_cast<const T16*>(p.w) + (int64_t)n * p.K + schunk * 8 : nullptr;
+        xsrc[j] = m < p.M ? reinterpret_cast<const T16*>(p.x) + (int64_t)m * p.ldx + schunk * 8 : nullptr;
+    }
+    auto stage = [&](int buf, int k0) {
+        const bool kok = k0 + schunk * 8 < p.K;
+        unsigned char* base = lds + buf * (2 * G_TILE_BYTES) + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const T16* s = (wsrc[j] && kok) ? wsrc[j] + k0 : zero;
+            __builtin_amdgcn_global_load_lds((const void*)s, (__attribute__((address_space(3))) void*)(base + j * 8192), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const T16* s = (xsrc[j] && kok) ? xsrc[j] + k0 : zero;
+            __builtin_amdgcn_global_load_lds((const void*)s, (__attribute__((address_space(3))) void*)(base + G_TILE_BYTES + j * 8192), 16, 0, 0);
+        }
+    };
+
+    // ---- fragment read offsets: lane -> row (lane & 15) of a 16-row tile, k chunk 4 ks + (lane >> 4), XOR ((row >> 1) & 7)
+    const int frow = lane & 15;
+    const int foff0 = frow * 128 + (((lane >> 4) ^ ((frow >> 1) & 7)) << 4);   // ks = 0; ks = 1: ^ 64
+    const int aoff = wn * (128 * 128) + foff0;                                 // W tile: rows wn * 128 + 16 i
+    const int boff = G_TILE_BYTES + wm * (64 * 128) + foff0;                   // X tile: rows wm * 64 + 16 j
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (p.K + GBK - 1) / GBK;
+    stage(0, 0);
+    __syncthreads();   // (emits vmcnt(0): the first tile has landed)
+    for (int t = 0; t < nkt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nkt) stage(buf ^ 1, (t + 1) * GBK);
+        const unsigned char* sb = lds + buf * (2 * G_TILE_BYTES);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            typename F::v8 af[8], bf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const typename F::v8*>(sb + ((boff + j * 2048) ^ (ks * 64)));
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const typename F::v8*>(sb + ((aoff + i * 2048) ^ (ks * 64)));
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = F::mfma(af[i], bf[j], acc[i][j]);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        __syncthreads();   // vmcnt(0) + barrier: tile t+1 has landed, every wave is done reading tile t
+    }
+
+    // ---- epilogue.  acc[i][j][r]: n = bn0 + wn*128 + 16 i + 4 (lane >> 4) + r, m = bm0 + wm*64 + 16 j + (lane & 15).
+    // No lane-dependent branch: loads go to clamped addresses, stores are buffer stores whose offset is pushed out of range
+    // for rows >= M / columns >= N (the hardware drops them) — a store under a branch costs a vmcnt(0) round trip per tile.
+    const int nl = bn0 + wn * 128 + (lane >> 4) * 4;
+    const int ml = bm0 + wm * 64 + (lane & 15);
+    f32x4 bv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int n = min(nl + i * 16, p.N - 4);
+        bv[i] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int rows_left = min(p.M - bm0, GBM);
+    if (EPI == 2) {
+        float* xb = p.x32 + (int64_t)bm0 * p.ldx32;   // descriptor over this tile's rows only
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (unsigned)rows_left * (unsigned)p.ldx32 * 4u, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = ml + j * 16;
+            const int mc = min(m, p.M - 1);
+            const float* gp = p.gate + (int64_t)(mc / p.T) * p.gate_stride;
+            const unsigned rowoff = (unsigned)(m - bm0) * (unsigned)p.ldx32 * 4u;
+            f32x4 xv[8], gv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int n = nl + i * 16;
+                const unsigned off = (m < p.M && n < p.N) ? rowoff + (unsigned)n * 4u : 0xFFFFFFF0u;
+                xv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));   // out of range -> 0
+                gv[i] = *reinterpret_cast<const f32x4*>(gp + min(n, p.N - 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int n = nl + i * 16;
+                const unsigned off = (m < p.M && n < p.N) ? rowoff + (unsigned)n * 4u : 0xFFFFFFF0u;
+                const f32x4 v = acc[i][j] + bv[i];
+                f32x4 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = fmaf(gv[i][e], (float)(T16)v[e], xv[i][e]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), rx, off, 0, 0);
+            }
+        }
+    } else {
+        T16* yb = reinterpret_cast<T16*>(p.y16) + (int64_t)bm0 * p.ldy;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (unsigned)rows_left * (unsigned)p.ldy * 2u, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = ml + j * 16;
+            const unsigned rowoff = (unsigned)(m - bm0) * (unsigned)p.ldy * 2u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int n = nl + i * 16;
+                const unsigned off = (m < p.M && n < p.N) ? rowoff + (unsigned)n * 2u : 0xFFFFFFF0u;
+                f32x4 v = acc[i][j] + bv[i];
+                if (EPI == 0 && n < p.qcols) v *= p.qscale;
+                typename F::v4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (T16)v[e];
+                if (EPI == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = (T16)gelu_tanh_f((float)h[e]);
+                }
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), ry, off, 0, 0);
+            }
+        }
+    }
+}
+
+template <typename T16>
+__global__ void cast16_kernel(const float* __restrict__ x, int64_t n, T16* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (T16)x[i];
+}
+template <typename T16>
+__global__ void uncast16_kernel(const T16* __restrict__ x, int64_t n, float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = (float)x[i];
+}
+
+// LayerNorm (no affine) + adaLN modulate of one token row per wave, 16-bit output; the row is read once (kept in registers)
+template <typename T16, int NV>   // NV float4 per lane: C <= 256 NV
+__global__ __launch_bounds__(256) void ln_modulate16_kernel(const float* __restrict__ x, int64_t rows, int T, int C,
+                                                            const float* __restrict__ mod, int mod_stride, int shift_off,
+                                                            int scale_off, float eps, T16* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    const float* mr = mod + (row / T) * mod_stride;
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        v[i] = c < C ? *reinterpret_cast<const f32x4*>(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < C) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = v[i][r] - mean;
+                q = fmaf(d, d, q);
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.f / sqrtf(q / C + eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < C) {
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(mr + scale_off + c);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(mr + shift_off + c);
+            typename Frag<T16>::v4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (T16)(((v[i][r] - mean) * rstd) * (1.f + sc[r]) + sh[r]);
+            *reinterpret_cast<typename Frag<T16>::v4*>(y + row * C + c) = h;
+        }
+    }
+}
+
+template <typename T16, int EPI>
+void launch_gemm16(const G16P& p, hipStream_t s) {
+    hipLaunchKernelGGL((gemm16_kernel<T16, EPI>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, s, p);
+}
+
+}  // namespace g16
+using namespace g16;
+
+bool gemm16_shape_ok(int M, int N, int K) { return M >= 1 && N >= 4 && K >= 8 && N % 4 == 0 && K % 8 == 0; }
+
+void gemm16(const Gemm16Args& a, hipStream_t s) {
+    DSD_CHECK(gemm16_shape_ok(a.M, a.N, a.K), "gemm16: M=%d N=%d K=%d unsupported (N %% 4, K %% 8)", a.M, a.N, a.K);
+    DSD_CHECK(a.ldx % 8 == 0 && a.ldx >= a.K, "gemm16: ldx=%d must be a multiple of 8 and >= K", a.ldx);
+    G16P p{};
+    p.x = a.x; p.w = a.w; p.bias = a.bias; p.y16 = a.y16; p.x32 = a.x32; p.gate = a.gate;
+    p.M = a.M; p.N = a.N; p.K = a.K; p.ldx = a.ldx; p.ldy = a.ldy; p.ldx32 = a.ldx32; p.gate_stride = a.gate_stride;
+    p.T = a.T > 0 ? a.T : 1;
+    p.qcols = a.qcols; p.qscale = a.qscale;
+    p.tiles_m = cdiv(a.M, GBM);
+    p.tiles_n = cdiv(a.N, GBN);
+    if (a.epi == EPI16_GATED) {
+        DSD_CHECK(a.x32 && a.gate && a.ldx32 % 4 == 0 && a.gate_stride % 4 == 0, "gemm16: gated epilogue needs x32 / gate (strides %% 4)");
+    } else {
+        DSD_CHECK(a.y16 && a.ldy % 4 == 0, "gemm16: 16-bit output missing or ldy %% 4 != 0");
+    }
+    if (a.bf16) {
+        switch (a.epi) {
+            case EPI16_STORE: launch_gemm16<__bf16, 0>(p, s); break;
+            case EPI16_GELU: launch_gemm16<__bf16, 1>(p, s); break;
+            default: launch_gemm16<__bf16, 2>(p, s); break;
+        }
+    } else {
+        switch (a.epi) {
+            case EPI16_STORE: launch_gemm16<_Float16, 0>(p, s); break;
+            case EPI16_GELU: launch_gemm16<_Float16, 1>(p, s); break;
+            default: launch_gemm16<_Float16, 2>(p, s); break;
+        }
+    }
+    check_launch("gemm16");
+}
+
+void cast16(const float* x, int64_t n, void* y, int bf16, hipStream_t s) {
+    if (!n) return;
+    const dim3 g((unsigned)std::min<int64_t>((n + 255) / 256, 65535));
+    if (bf16) hipLaunchKernelGGL(cast16_kernel<__bf16>, g, dim3(256), 0, s, x, n, (__bf16*)y);
+    else hipLaunchKernelGGL(cast16_kernel<_Float16>, g, dim3(256), 0, s, x, n, (_Float16*)y);
+    check_launch("cast16");
+}
+void uncast16(const void* x, int64_t n, float* y, int bf16, hipStream_t s) {
+    if (!n) return;
+    const dim3 g((unsigned)std::min<int64_t>((n + 255) / 256, 65535));
+    if (bf16) hipLaunchKernelGGL(uncast16_kernel<__bf16>, g, dim3(256), 0, s, (const __bf16*)x, n, y);
+    else hipLaunchKernelGGL(uncast16_kernel<_Float16>, g, dim3(256), 0, s, (const _Float16*)x, n, y);
+    check_launch("uncast16");
+}
+
+void ln_modulate16(const float* x, int N, int T, int C, const float* mod, int mod_stride, int shift_off, int scale_off, float eps,
+                   void* y, int bf16, hipStream_t s) {
+    const int64_t rows = (int64_t)N * T;
+    if (rows == 0) return;
+    DSD_CHECK(C % 4 == 0 && C <= 2048 && mod_stride % 4 == 0 && shift_off % 4 == 0 && scale_off % 4 == 0,
+              "ln_modulate16: C=%d must be a multiple of 4 and <= 2048 (strides %% 4)", C);
+    const dim3 g(cdiv(rows, 4)), b(256);
+    const int nv = cdiv(C, 256);
+#define LN16(TT, NV) hipLaunchKernelGGL((ln_modulate16_kernel<TT, NV>), g, b, 0, s, x, rows, T, C, mod, mod_stride, shift_off, scale_off, eps, (TT*)y)
+    if (bf16) {
+        if (nv <= 1) LN16(__bf16, 1); else if (nv <= 2) LN16(__bf16, 2); else if (nv <= 3) LN16(__bf16, 3);
+        else if (nv <= 4) LN16(__bf16, 4); else if (nv <= 5) LN16(__bf16, 5); else LN16(__bf16, 8);
+    } else {
+        if (nv <= 1) LN16(_Float16, 1); else if (nv <= 2) LN16(_Float16, 2); else if (nv <= 3) LN16(_Float16, 3);
+        else if (nv <= 4) LN16(_Float16, 4); else if (nv <= 5) LN16(_Float16, 5); else LN16(_Float16, 8);
+    }
+#undef LN16
+    check_launch("ln_modulate16");
+}
+
+}  // namespace dsd

@@ -56,7 +56,7 @@ inline void conv_out_hw(const ConvArgs& a, int* OH, int* OW) {
 // chunks per sample the kernel conv2d() will launch for these arguments can emit output statistics with (0 = it cannot:
 // the caller runs gn_stats on the output instead)
 int conv2d_stats_chunks(const ConvArgs& a);
-enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16X6 = 2, PREC_F16X3 = 3 };
+enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16X6 = 2, PREC_F16X3 = 3, PREC_F16 = 4, PREC_BF16 = 5 };
 void conv2d(ConvArgs a, hipStream_t s);
 // conv_split.hip: fp32 operands as sums of bf16 pieces on the bf16 matrix cores
 void split_weights(const float* w, int64_t n, int np, void* planes, hipStream_t s, bool f16 = false, int* ovf = nullptr);
@@ -124,6 +124,47 @@ struct AttnArgs {
     int split = 0;         // 1: both products on the bf16 matrix cores with operands split into 3 bf16 pieces (bf16x6), 0: fp32 MFMA
 };
 void attention(const AttnArgs& a, hipStream_t s);
+
+// ---------------------------------------------------------------- gemm16.hip / attention16.hip
+// Single-product half-precision arithmetic of the transformer backbone (PREC_F16 / PREC_BF16: 16-bit operands, one MFMA per
+// product, fp32 accumulation) — what the reference's DiT runs under fp16 autocast (BASELINE configs[4]).
+enum { EPI16_STORE = 0, EPI16_GELU = 1, EPI16_GATED = 2 };
+struct Gemm16Args {
+    const void* x = nullptr;   // [M][ldx] 16-bit activations
+    int ldx = 0;
+    const void* w = nullptr;   // [N][K] 16-bit weights (nn.Linear layout)
+    const float* bias = nullptr;
+    int M = 0, N = 0, K = 0;
+    int bf16 = 0;              // 0: fp16, 1: bf16
+    int epi = EPI16_STORE;
+    void* y16 = nullptr;       // EPI16_STORE / EPI16_GELU: [M][ldy] 16-bit
+    int ldy = 0;
+    float* x32 = nullptr;      // EPI16_GATED: x32[m][n] += gate[(m / T) * gate_stride + n] * round16(acc + bias)
+    int ldx32 = 0;
+    const float* gate = nullptr;
+    int gate_stride = 0, T = 1;
+    int qcols = 0;             // EPI16_STORE: columns < qcols are multiplied by qscale in fp32 before the rounding
+    float qscale = 1.f;
+};
+bool gemm16_shape_ok(int M, int N, int K);
+void gemm16(const Gemm16Args& a, hipStream_t s);
+void cast16(const float* x, int64_t n, void* y, int bf16, hipStream_t s);      // fp32 -> fp16 / bf16, round to nearest even
+void uncast16(const void* x, int64_t n, float* y, int bf16, hipStream_t s);
+// ln_modulate (misc.hip) with a 16-bit result: the A operand of the following Linear
+void ln_modulate16(const float* x, int N, int T, int C, const float* mod, int mod_stride, int shift_off, int scale_off, float eps,
+                   void* y, int bf16, hipStream_t s);
+struct Attn16Args {
+    const void *q = nullptr, *k = nullptr, *v = nullptr;   // 16-bit rows of ld* elements, head h at +h*hs*
+    int ldq = 0, ldk = 0, ldv = 0, ldo = 0;
+    int q_hs = 0, k_hs = 0, v_hs = 0;
+    int N = 0, Tq = 0, Tk = 0, heads = 0, d = 0;
+    float scale_q = 1.f;   // q * scale_q (fp32, rounded back) — 1 when q arrives pre-scaled by hd^-1/2 * log2(e); scores are base-2 logits
+    float thr = -1.f;      // running-maximum threshold in log2 units (< 0: default 8; 0: move the maximum on every increase)
+    int bf16 = 0;
+    void* out = nullptr;   // [N][Tq][ldo] 16-bit, head h at +h*d
+};
+bool attention16_shape_ok(int d);
+void attention16(const Attn16Args& a, hipStream_t s);
 
 // ---------------------------------------------------------------- misc.hip
 void timestep_embedding(const void* t, int t_is_float, int N, int dim, float* y, hipStream_t s,

@@ -565,11 +565,18 @@ void dsd::net_drop_graph(dsd_handle* h) {
 
 void dsd::net_drop_other_pieces(dsd_handle* h, int precision) {
     if (precision == PREC_F32) return;   // the exact mode needs none, but switching back should not re-split everything
-    const bool keep_f16 = precision == PREC_F16X3;
+    // which family a cached entry belongs to, by the suffix of its key: "#f16" two fp16 pieces (f16x3), "#h16" / "#b16" the
+    // single fp16 / bf16 copy of the half-precision modes, anything else the bf16 pieces (bf16x3 / bf16x6, also what the
+    // half-precision modes keep for the layers that stay fp32-grade)
+    auto ends = [](const std::string& k, const char* sfx) { return k.size() > 4 && k.compare(k.size() - 4, 4, sfx) == 0; };
     bool any = false;
     for (auto it = h->wsplit.begin(); it != h->wsplit.end();) {
-        const bool is_f16 = it->first.size() > 4 && it->first.compare(it->first.size() - 4, 4, "#f16") == 0;
-        if (is_f16 != keep_f16) {
+        bool keep;
+        if (ends(it->first, "#f16")) keep = precision == PREC_F16X3;
+        else if (ends(it->first, "#h16")) keep = precision == PREC_F16;
+        else if (ends(it->first, "#b16")) keep = precision == PREC_BF16;
+        else keep = precision != PREC_F16X3;
+        if (!keep) {
             if (!any) DSD_HIP(hipDeviceSynchronize());
             any = true;
             (void)hipFree(it->second);
@@ -628,11 +635,71 @@ struct Builder {
     bool split_any = false;
     Builder(dsd_handle* h, Plan& p, int b, hipStream_t s) : hd(h), plan(p), B(b), ps(s) {}
 
-    Tn alloc(int n, int h, int w, int c) {
+    Tn alloc(int n, int h, int w, int c, int esz = 4) {
         Tn t;
-        t.n = n; t.h = h; t.w = w; t.c = c;
+        t.n = n; t.h = h; t.w = w; t.c = c; t.esz = esz;
         t.off = ar.alloc(t.bytes());
         return t;
+    }
+    // arithmetic of the convolution kernels: the half-precision modes (DiT) keep their few non-transformer layers fp32-grade
+    int conv_prec() const { return hd->precision >= PREC_F16 ? PREC_BF16X6 : hd->precision; }
+    bool half_mode() const { return hd->precision == PREC_F16 || hd->precision == PREC_BF16; }
+    // 16-bit copy of a Linear weight [N][K] (made once per mode at plan time, on the caller's stream)
+    const void* w16(const std::string& name) {
+        const bool bf = hd->precision == PREC_BF16;
+        const std::string key = name + (bf ? "#b16" : "#h16");
+        auto it = hd->wsplit.find(key);
+        if (it == hd->wsplit.end()) {
+            const Param& pw = hd->PP(name);
+            void* buf = nullptr;
+            DSD_HIP(hipMalloc(&buf, (size_t)pw.numel * 2));
+            cast16(W(name), pw.numel, buf, bf ? 1 : 0, ps);
+            split_any = true;
+            it = hd->wsplit.emplace(key, buf).first;
+            hd->wsplit_bytes[key] = (size_t)pw.numel * 2;
+        }
+        return it->second;
+    }
+    // nn.Linear on 16-bit operands (gemm16.hip).  x: 16-bit tokens [n, h*w, K].  epi EPI16_STORE / EPI16_GELU: returns the
+    // 16-bit result; EPI16_GATED: xres (fp32) += gate * result, returns xres.
+    Tn linear16(const std::string& name, const Tn& x, int cout, int epi, const Tn* xres = nullptr, size_t gate_off = 0,
+                int gate_col = 0, int gate_stride = 0, int qcols = 0, float qscale = 1.f) {
+        DSD_CHECK(x.esz == 2, "linear16 %s: 16-bit input expected", name.c_str());
+        const Param& pw = hd->PP(name + ".weight");
+        const int K = x.c, M = x.n * x.hw(), T = x.hw();
+        DSD_CHECK(pw.numel == (int64_t)cout * K, "linear %s: weight has %lld elements, graph expects %dx%d", name.c_str(),
+                  (long long)pw.numel, cout, K);
+        Gemm16Args a;
+        a.w = w16(name + ".weight");
+        a.bias = W(name + ".bias");
+        a.M = M; a.N = cout; a.K = K; a.ldx = K; a.bf16 = hd->precision == PREC_BF16; a.epi = epi;
+        a.qcols = qcols; a.qscale = qscale;
+        Tn y;
+        if (epi == EPI16_GATED) {
+            DSD_CHECK(xres && xres->esz == 4 && xres->c == cout && xres->n * xres->hw() == M, "linear16 %s: residual stream mismatch", name.c_str());
+            y = *xres;
+            a.ldx32 = cout; a.gate_stride = gate_stride; a.T = T;
+        } else {
+            y = alloc(x.n, x.h, x.w, cout, 2);
+            a.ldy = cout;
+        }
+        const size_t xoff = x.off, yoff = y.off;
+        dsd_handle* h = hd;
+        const double fl = 2.0 * M * (double)cout * K;
+        plan.flops += fl;
+        op([=](hipStream_t s) {
+            Gemm16Args c = a;
+            c.x = h->arena + xoff;
+            if (epi == EPI16_GATED) {
+                c.x32 = reinterpret_cast<float*>(h->arena + yoff);
+                c.gate = reinterpret_cast<const float*>(h->arena + gate_off) + gate_col;
+            } else {
+                c.y16 = h->arena + yoff;
+            }
+            gemm16(c, s);
+        }, 1, epi == EPI16_GATED ? "gemm16_gated" : (epi == EPI16_GELU ? "gemm16_gelu" : "gemm16"), fl,
+           2.0 * ((double)M * K + (double)cout * K) + (epi == EPI16_GATED ? 8.0 : 2.0) * M * cout);
+        return y;
     }
     void release(Tn& t) {
         if (t.valid()) ar.release(t.off, t.bytes());
@@ -690,8 +757,9 @@ struct Builder {
         }
         const int y_ld = dst ? dst->c : 0;
         if (res) DSD_CHECK(res->n == x.n && res->h == OH && res->w == OW && res->c == cout, "conv %s: residual shape mismatch", name.c_str());
-        if (hd->precision != PREC_F32 && x.c % 32 == 0 && plane < 0) {   // split-bf16 arithmetic: pieces of the (packed) weight
-            const bool f16 = hd->precision == PREC_F16X3;
+        const int prec = conv_prec();
+        if (prec != PREC_F32 && x.c % 32 == 0 && plane < 0) {   // split-bf16 arithmetic: pieces of the (packed) weight
+            const bool f16 = prec == PREC_F16X3;
             const std::string key = f16 ? name + "#f16" : name;
             auto it = hd->wsplit.find(key);
             if (it == hd->wsplit.end()) {
@@ -708,7 +776,7 @@ struct Builder {
                 hd->wsplit_bytes[key] = (size_t)pw.numel * 2 * 3;
             }
             a.w_split = it->second;
-            a.precision = hd->precision;
+            a.precision = prec;
             a.ovf = f16 ? hd->ovf : nullptr;
             // 3x3 stride-1 layers with enough tiles: F(2,3)-along-W kernel (conv_wino.hip), transformed weights packed once
             if (hd->use_winograd && conv2d_wino_worthwhile(a)) {
@@ -879,7 +947,7 @@ struct Builder {
     }
     // would conv(name, x, cout, 3) apply the GroupNorm + SiLU of its input by itself?  (the tap-reuse kernel, bf16x6 only)
     bool can_fuse_gn(const Tn& x, int cout) {
-        if (!hd->fuse_gn_apply || hd->precision != PREC_BF16X6 || x.c % 32 != 0) return false;
+        if (!hd->fuse_gn_apply || conv_prec() != PREC_BF16X6 || x.c % 32 != 0) return false;
         ConvArgs a;
         a.N = x.n; a.H = x.h; a.W = x.w; a.Cin = x.c; a.Cout = cout; a.ks = 3; a.stride = 1;
         a.precision = PREC_BF16X6;
@@ -1645,9 +1713,22 @@ void build_dit(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
                 cc += (int)pr.numel;
             }
     }
-    auto ln_mod = [&](const Tn& src, int mcol, int shift_off, int scale_off) {
-        Tn y = b.alloc(src.n, src.h, src.w, src.c);
+    // half-precision modes: the four Linears and the attention of every block take 16-bit operands (gemm16.hip,
+    // attention16.hip); shapes those kernels do not take (widths not multiples of 8, head dims beyond 128) keep bf16x6
+    const int hdim0 = D / c.heads;
+    const bool h16 = b.half_mode() && gemm16_shape_ok(B * T, D, D) && gemm16_shape_ok(B * T, D, c.mlp) && c.mlp % 8 == 0 &&
+                     D % c.heads == 0 && attention16_shape_ok(hdim0);
+    const int bf = hd->precision == PREC_BF16 ? 1 : 0;
+    auto ln_mod = [&](const Tn& src, int mcol, int shift_off, int scale_off, bool out16 = false) {
+        Tn y = b.alloc(src.n, src.h, src.w, src.c, out16 ? 2 : 4);
         const size_t so = src.off, yo = y.off, mo = mod.off;
+        if (out16) {
+            b.op([=](hipStream_t s) {
+                ln_modulate16(reinterpret_cast<const float*>(hd->arena + so), B, T, D, reinterpret_cast<const float*>(hd->arena + mo) + mcol,
+                              etot, shift_off, scale_off, 1e-6f, hd->arena + yo, bf, s);
+            }, 1, "ln_modulate16", 0.0, 6.0 * B * T * D);
+            return y;
+        }
         b.op([=](hipStream_t s) {
             ln_modulate(reinterpret_cast<const float*>(hd->arena + so), B, T, D, reinterpret_cast<const float*>(hd->arena + mo) + mcol, etot,
                         shift_off, scale_off, 1e-6f, reinterpret_cast<float*>(hd->arena + yo), s);
@@ -1665,6 +1746,41 @@ void build_dit(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
     for (int i = 0; i < c.depth; ++i) {   // DiTBlock.forward :118-122
         const std::string bp = "blocks." + std::to_string(i);
         const int mc = col.at(bp + ".adaLN_modulation.1");   // chunk(6): shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+        if (h16) {
+            // x = x + gate_msa * proj(attn(qkv(modulate(norm1(x)))));  x = x + gate_mlp * fc2(gelu(fc1(modulate(norm2(x)))))
+            // q leaves the qkv GEMM multiplied by hd^-1/2 log2(e) (one rounding): the attention kernel works on base-2 logits
+            Tn n1 = ln_mod(x, mc, 0, D, true);
+            Tn qkv = b.linear16(bp + ".attn.qkv", n1, 3 * D, EPI16_STORE, nullptr, 0, 0, 0, D,
+                                1.4426950408889634f / std::sqrt((float)hdim0));
+            b.release(n1);
+            Tn a = b.alloc(B, T, 1, D, 2);
+            {
+                Attn16Args aa;
+                aa.N = B; aa.Tq = T; aa.Tk = T; aa.heads = c.heads; aa.d = hdim0;
+                aa.ldq = aa.ldk = aa.ldv = 3 * D; aa.ldo = D;
+                aa.q_hs = aa.k_hs = aa.v_hs = hdim0;
+                aa.bf16 = bf;
+                const size_t qo = qkv.off, ao = a.off;
+                const double fl = 4.0 * B * c.heads * (double)T * T * hdim0;
+                b.plan.flops += fl;
+                b.op([=](hipStream_t s) {
+                    Attn16Args r = aa;
+                    const char* base = hd->arena + qo;
+                    r.q = base; r.k = base + (size_t)D * 2; r.v = base + (size_t)2 * D * 2;
+                    r.out = hd->arena + ao;
+                    attention16(r, s);
+                }, 1, "attention16", fl, 2.0 * B * T * 4.0 * D);
+            }
+            b.release(qkv);
+            b.linear16(bp + ".attn.proj", a, D, EPI16_GATED, &x, mod.off, mc + 2 * D, etot);
+            b.release(a);
+            Tn n2 = ln_mod(x, mc, 3 * D, 4 * D, true);
+            Tn h1 = b.linear16(bp + ".mlp.fc1", n2, c.mlp, EPI16_GELU);
+            b.release(n2);
+            b.linear16(bp + ".mlp.fc2", h1, D, EPI16_GATED, &x, mod.off, mc + 5 * D, etot);
+            b.release(h1);
+            continue;
+        }
         Tn n1 = ln_mod(x, mc, 0, D);
         Tn qkv = b.conv(bp + ".attn.qkv", n1, 3 * D, 1);
         b.release(n1);

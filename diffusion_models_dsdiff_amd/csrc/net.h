@@ -33,10 +33,11 @@ struct StatRef {
 struct Tn {
     size_t off = (size_t)-1;
     int n = 0, h = 0, w = 0, c = 0;
+    int esz = 4;     // bytes per element: 4 (fp32) everywhere but the 16-bit activations of DSD_PREC_F16 / DSD_PREC_BF16
     StatRef st[2];   // st[0] covers channels [0, st[0].c); st[1] (concatenated tensors) the rest
     bool valid() const { return off != (size_t)-1; }
     int64_t numel() const { return (int64_t)n * h * w * c; }
-    size_t bytes() const { return (size_t)numel() * sizeof(float); }
+    size_t bytes() const { return (size_t)numel() * esz; }
     int hw() const { return h * w; }
 };
 

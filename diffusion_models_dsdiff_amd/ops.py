@@ -19,7 +19,7 @@ def to_nchw(x: torch.Tensor) -> torch.Tensor:
     return x.permute(0, 3, 1, 2).contiguous()
 
 
-PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}
+PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3}   # the convolution modes (f16 / bf16 are DiT-handle modes)
 
 
 STRUCTURES = {"auto": 0, "adirect": 16, "staged": 32, "adirect256": 64, "winograd": 128}
@@ -51,6 +51,29 @@ def qkv_attention(qkv_ntc, heads, new_order=True, split=False):
     N, T, C3 = qkv_ntc.shape
     a = torch.empty((N, T, C3 // 3), device=qkv_ntc.device, dtype=torch.float32)
     check(lib().dsd_op_qkv_attention(dptr(qkv_ntc), N, T, C3 // 3, heads, int(new_order), int(split), dptr(a), stream_ptr()))
+    return a
+
+
+def gemm_half(x, w, bias=None, dtype="f16", epi="store", gate=None, T=1, y=None):
+    """nn.Linear on 16-bit operands (one MFMA per product, fp32 accumulation): y = x w^T + bias.  epi "store" | "gelu" |
+    "gated" (y fp32 in/out: y += gate[m // T] * round16(x w^T + bias))."""
+    M, K = x.shape
+    N = w.shape[0]
+    e = {"store": 0, "gelu": 1, "gated": 2}[epi]
+    if e == 2:
+        assert y is not None and gate is not None
+    else:
+        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+    check(lib().dsd_op_gemm_half(dptr(x), dptr(w.contiguous()), dptr(bias), M, N, K, int(dtype == "bf16"), e, dptr(gate), int(T),
+                                 dptr(y), stream_ptr()))
+    return y
+
+
+def attention_half(qkv_ntc, heads, dtype="f16", thr=-1.0):
+    """timm Attention core on qkv[N,T,3C] (q | k | v): softmax(q k^T d^-1/2) v with 16-bit operands, fp32 statistics."""
+    N, T, C3 = qkv_ntc.shape
+    a = torch.empty((N, T, C3 // 3), device=qkv_ntc.device, dtype=torch.float32)
+    check(lib().dsd_op_attention_half(dptr(qkv_ntc), N, T, C3 // 3, heads, int(dtype == "bf16"), float(thr), dptr(a), stream_ptr()))
     return a
 
 

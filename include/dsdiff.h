@@ -90,8 +90,14 @@ int dsd_set_timestep_freqs(dsd_handle* h, const float* freqs_host, int n);
  * synchronisation at the end of dsd_forward / dsd_sample) instead of returning inf/NaN, and operands that are uniformly
  * tiny lose accuracy (absolute floor 3e-8: |x|~1e-3 -> 2e-5 relative).  Meant for GroupNorm-normalised activations.
  * Default: DSD_PREC_BF16X6 (all parity tests hold at the fp32 tolerances); shapes the split kernel cannot take
- * (Cin % 32 != 0, operands >= 4 GiB) use the fp32 kernels in every mode. */
-enum { DSD_PREC_F32 = 0, DSD_PREC_BF16X3 = 1, DSD_PREC_BF16X6 = 2, DSD_PREC_F16X3 = 3 };
+ * (Cin % 32 != 0, operands >= 4 GiB) use the fp32 kernels in every mode.
+ * DSD_PREC_F16 / DSD_PREC_BF16 (DSD_BLOCK_DIT handles only; any other handle refuses them): the reference's autocast
+ * arithmetic for the transformer backbone (BASELINE configs[4] "512x512 fp16"; UNet_DS_Diff/DiT_models.py:101-122 under
+ * torch.autocast) — the four Linears of every DiTBlock and both attention products take 16-bit operands rounded ONCE
+ * (round to nearest even) and run ONE MFMA per product with fp32 accumulation; LayerNorm, adaLN modulation, softmax
+ * statistics, the gated residual stream, patch embedding, conditioning MLPs and the final layer stay fp32 as autocast keeps
+ * them.  fp16 has fp16's range (activations beyond 65504 become inf exactly as in the reference); bf16 does not. */
+enum { DSD_PREC_F32 = 0, DSD_PREC_BF16X3 = 1, DSD_PREC_BF16X6 = 2, DSD_PREC_F16X3 = 3, DSD_PREC_F16 = 4, DSD_PREC_BF16 = 5 };
 int dsd_set_precision(dsd_handle* h, int precision);
 int dsd_get_precision(dsd_handle* h);
 /* dsd_sample only, OFF by default.  In the 2-channel branch (model.py:654-658) the `al` and `l` encoder streams get
@@ -329,6 +335,15 @@ int dsd_op_group_norm(const float* x, int N, int HW, int C, const float* gamma, 
  * the fp32 matrix cores (what DSD_PREC_F32 runs); 1: operands split exactly into three bf16 pieces, six bf16 MFMA products
  * each (what every other mode runs); the softmax is fp32 either way. */
 int dsd_op_qkv_attention(const float* qkv, int N, int T, int C, int heads, int new_order, int split, float* a, void* stream);
+/* The half-precision kernels of DSD_PREC_F16 / DSD_PREC_BF16 on fp32 device buffers (the entry rounds the inputs to 16 bits
+ * once, runs the kernel, and widens the 16-bit result): y[M,N] = x[M,K] w[N,K]^T + bias (nn.Linear; timm Mlp / Attention
+ * projections, DiT_models.py:101-122).  epi 0: y = round16(acc + bias); 1: y = round16(gelu_tanh(round16(acc + bias)));
+ * 2: y (fp32, in/out) += gate[(m / T), :] * round16(acc + bias) — the adaLN-Zero gated residual (:120-121). */
+int dsd_op_gemm_half(const float* x, const float* w, const float* bias, int M, int N, int K, int bf16, int epi,
+                     const float* gate, int T, float* y, void* stream);
+/* softmax(q k^T * d^-1/2) v of timm Attention on qkv[N,T,3C] (q | k | v, heads inside each) -> a[N,T,C], 16-bit operands,
+ * fp32 softmax statistics; thr: running-maximum threshold in log2 units (< 0: the library's default). */
+int dsd_op_attention_half(const float* qkv, int N, int T, int C, int heads, int bf16, float thr, float* a, void* stream);
 /* timestep_embedding (util.py:161-181): t[N] (int64 or fp32) -> [N,dim].  freqs (device, [dim/2], may be NULL): the
  * frequency table as the caller's own fp32 exp evaluates it (what dsd_set_timestep_freqs installs in a model handle);
  * with it the sin/cos arguments are bit-identical to the reference's. */
