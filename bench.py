@@ -63,11 +63,17 @@ def issued_peak(precision):
     return PEAK_FP32_MFMA_TFLOPS if precision == "f32" else PEAK_16BIT_MFMA_TFLOPS
 
 
+def headline_args(args):
+    return (args.batch == HEADLINE["batch"] and args.size == HEADLINE["size"] and args.model_channels is None
+            and os.path.abspath(args.config) == os.path.join(ROOT, "configs", "v2-1-cddpm-ds-disc.yaml"))
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--repeats", type=int, default=3, help="the K timed steps are run this many times; value = median repeat")
     ap.add_argument("--batch", type=int, default=16, help="slices per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "v2-1-cddpm-ds-disc.yaml"))
@@ -77,6 +83,7 @@ def parse_args(argv=None):
     ap.add_argument("--precision", default=os.environ.get("DSD_PRECISION", "bf16x6"), choices=list(PASSES),
                     help="arithmetic of the convolutions (include/dsdiff.h: dsd_set_precision); default = library default")
     ap.add_argument("--no-modes", action="store_true", help="do not also time the other arithmetic modes")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the BASELINE configs[2..4] lines (BraTS DDIM, latent path, DiT)")
     ap.add_argument("--graph", action="store_true", help="replay the captured hipGraph of a step instead of launching every "
                                                          "kernel from the host (measured equal at batch 16, no gain at batch 1)")
     ap.add_argument("--winograd", action="store_true", help="bf16x6 only: the F(2,3)-along-W kernel for the large 3x3 layers "
@@ -137,11 +144,32 @@ def cpu_baseline(unet_params, sd, H, W, budget_s):
     from oracle import unet as O
     from oracle.synth import randn
     cfg = O.UNetConfig.from_params(unet_params)
-    # the GPU box reports every host core but a 1-GPU job owns a share of them: use the affinity mask, at most 32 threads
+    # Cores: everything this job may run on — the affinity mask, cut to the cgroup CPU quota when the container has one (a
+    # 1-GPU job on the GPU box sees all 256 host threads in its mask but owns a share of them: 256 oversubscribed threads
+    # measured 258 s per forward where 32 take 5.5 s).  Where neither bound is informative the thread count is PROBED: one
+    # 64x64 forward per candidate, the fastest wins.  `cores` in the report = the threads actually used.
     try:
-        n = min(len(os.sched_getaffinity(0)), 32)
+        n_aff = len(os.sched_getaffinity(0))
     except AttributeError:
-        n = min(os.cpu_count() or 1, 32)
+        n_aff = os.cpu_count() or 1
+    quota = cgroup_cpu_quota()
+    probe = None
+    if quota is not None:
+        n = max(1, min(n_aff, int(quota + 0.5)))
+    elif n_aff <= 32:
+        n = n_aff
+    else:
+        probe = {}
+        xp, tp = randn((1, 2, 64, 64), 8), torch.tensor([500])
+        for cand in sorted({c for c in (16, 32, 64, 128, n_aff) if c <= n_aff}):
+            torch.set_num_threads(cand)
+            O.unet_forward(cfg, sd, xp, tp)                      # (first call at this thread count: pool start-up)
+            t0 = time.time()
+            O.unet_forward(cfg, sd, xp, tp)
+            probe[cand] = round(time.time() - t0, 3)
+            if probe[cand] > 3.0 * min(probe.values()):
+                break                                            # clearly past the knee: do not try more threads
+        n = min(probe, key=probe.get)
     torch.set_num_threads(n)
     x = randn((1, 2, H, W), 7)
     t = torch.tensor([500])
@@ -154,10 +182,39 @@ def cpu_baseline(unet_params, sd, H, W, budget_s):
         if time.time() - t_start + times[-1] > budget_s or len(times) >= 5:
             break
     step = sorted(times)[len(times) // 2]
-    rep = {"value": 1.0 / (1000.0 * step), "unit": "slices/s", "cores": n, "kind": "port",
+    rep = {"value": 1.0 / (1000.0 * step), "unit": "slices/s", "cores": n, "cpu_model": cpu_model(), "host_cores_total": os.cpu_count(),
+           "affinity_cores": n_aff, "cgroup_cpu_quota": quota, "thread_probe_s_per_64x64_forward": probe, "kind": "port",
            "sample": f"{len(times)} forward(s) of the same U-Net at {H}x{W}, batch 1, fp32, torch-CPU oracle, "
                      f"median {step:.2f} s/step, extrapolated x1000 steps"}
     return rep, x, t, y
+
+
+def cgroup_cpu_quota():
+    """CPUs this container may use per the cgroup controller (v2 cpu.max, v1 cfs quota / period), or None."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return q / per
+    except (OSError, ValueError):
+        pass
+    return None
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
 
 
 def kernel_symbol(kind):
@@ -201,26 +258,35 @@ class StubLeg:
         self.dev = torch.device("cpu")
         self.x = torch.full((args.batch, 1, 8, 8), float(rank))
         self.gpu_name, self.n_cu, self.n_params, self.t_setup, self.bcast_ms = "stub", 0, 0, 0.0, None
+        self.bcast_buckets = None
         if world > 1:
-            import torch.distributed as dist
-            flat = torch.full((1024,), float(rank))
+            # the same bucketed weight broadcast the GPU leg runs, on a small fake parameter table: only rank 0 holds values
+            from diffusion_models_dsdiff_amd import parallel
+            named = [("a.weight", (1000,)), ("b.weight", (3, 1000)), ("c.bias", (10,)), ("d.weight", (7, 11))]
+            src = {nm: torch.arange(parallel._numel(sh), dtype=torch.float32).reshape(sh) + i for i, (nm, sh) in enumerate(named)}
+            got = {}
             t0 = time.time()
-            dist.broadcast(flat, 0)
+            self.bcast_buckets = parallel.broadcast_params_bucketed(named, (lambda nm: src[nm]) if rank == 0 else None,
+                                                                    lambda nm, t: got.__setitem__(nm, t.clone()), 0, None, 2048)
             self.bcast_ms = (time.time() - t0) * 1e3
-            assert float(flat[0]) == 0.0
+            assert self.bcast_buckets == 3 and all(torch.equal(got[nm], src[nm]) for nm, _ in named)
 
     def sync(self):
         pass
 
-    def measure(self, precision, steps, warmup, profile_steps, barrier, reduce_max):
-        barrier()
-        t1 = time.time()
-        for _ in range(steps):
-            time.sleep(0.002 * (1 + self.rank))
-        barrier()
-        dt = time.time() - t1
-        ms, per_rank = reduce_max(dt / steps * 1e3)
+    def measure(self, precision, steps, warmup, profile_steps, barrier, reduce_max, repeats=1):
+        reps = []
+        for _ in range(max(1, repeats)):
+            barrier()
+            t1 = time.time()
+            for _ in range(steps):
+                time.sleep(0.002 * (1 + self.rank))
+            barrier()
+            reps.append(reduce_max((time.time() - t1) / steps * 1e3))
+        ms, per_rank = sorted(reps, key=lambda r: r[0])[len(reps) // 2]
         return {"precision": precision, "ms_per_step": round(ms, 3), "per_rank_ms_per_step": per_rank,
+                "timing": {"method": "time.time() around K sleeps (stub)", "repeats": len(reps),
+                           "ms_per_step_repeats": [round(r[0], 3) for r in reps]},
                 "value": round((self.args.batch * self.world) / (1000.0 * ms / 1e3), 6), "whole_step_tflops": 0.0,
                 "finite": True, "info": {"workspace_bytes": 0, "launches": 0, "flops": 0.0}, "roofline": None,
                 "kernels": None}
@@ -245,29 +311,34 @@ class GpuLeg:
         if args.model_channels:
             uc["params"]["model_channels"] = args.model_channels
         self.unet_params = uc["params"]
+        from diffusion_models_dsdiff_amd import parallel
         torch.manual_seed(2024)
         t0 = time.time()
-        self.model = model = instantiate_from_config(uc)
+        # only rank 0 initialises the 981.5 M parameters on its host; the others allocate storage and receive the values
+        if rank == 0:
+            self.model = model = instantiate_from_config(uc)
+            synth_weights_(model, 2024)
+        else:
+            with parallel.empty_init():
+                self.model = model = instantiate_from_config(uc)
         model.set_precision(args.precision)
         model.use_graph(args.graph)
         model.winograd(args.winograd)
-        synth_weights_(model, 2024)
         self.n_params = sum(p.numel() for p in model.parameters())
-        # one-off weight distribution: rank 0's parameters broadcast as ONE packed blob over RCCL/xGMI
-        self.bcast_ms = None
+        # one-off weight distribution (the analogue of Disc_diff/guided_diffusion/dist_util.py:54-83): rank 0's parameters in
+        # 256 MB buckets over RCCL/xGMI, every bucket uploaded into the library's slab straight from the receive buffer
+        self.bcast_ms, self.bcast_buckets = None, None
         if world > 1:
-            import torch.distributed as dist
-            flat = torch.cat([p.data.reshape(-1) for p in model.parameters()]).to(dev)
+            named = [(nm, tuple(p.shape)) for nm, p in model.named_parameters()]
+            src = dict(model.named_parameters()) if rank == 0 else None
             torch.cuda.synchronize()
             tb = time.time()
-            dist.broadcast(flat, 0)
+            self.bcast_buckets = parallel.broadcast_params_bucketed(named, (lambda nm: src[nm]) if rank == 0 else None,
+                                                                    model.upload_param, 0, dev)
             torch.cuda.synchronize()
             self.bcast_ms = (time.time() - tb) * 1e3
-            off = 0
-            for p in model.parameters():
-                p.data = flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
-        model.sync_params(force=True)
+        else:
+            model.sync_params(force=True)
         self.t_setup = time.time() - t0
         B, H, W = args.batch, args.size, args.size
         diffusion = create_gaussian_diffusion(steps=mp.get("diffusion_steps", 1000), learn_sigma=mp.get("learn_sigma", False),
@@ -285,8 +356,12 @@ class GpuLeg:
     def sync(self):
         torch.cuda.synchronize()
 
-    def measure(self, precision, steps, warmup, profile_steps, barrier, reduce_max):
-        """K timed denoising steps in one arithmetic mode (+ optional per-kernel hipEvent pass on rank 0)."""
+    def measure(self, precision, steps, warmup, profile_steps, barrier, reduce_max, repeats=1):
+        """K timed denoising steps in one arithmetic mode, `repeats` times (+ optional per-kernel hipEvent pass on rank 0).
+        Every repeat is bracketed by barrier + synchronize on both sides and timed twice: by hipEvents recorded on the
+        stream the steps are launched on (torch's current stream = the one handed to dsd_sample) and by the host clock;
+        per repeat the MAX over ranks counts, the reported step time is the MEDIAN repeat of the event timing
+        (boxes differ by +-4 %, launches are asynchronous)."""
         from diffusion_models_dsdiff_amd import _lib
         from diffusion_models_dsdiff_amd._sched import run_device_loop
         model, sched, cond = self.model, self.sched, self.cond
@@ -296,14 +371,29 @@ class GpuLeg:
             self.x = run_device_loop(model, sched, self.x, cond, seed=1234, first_step=0, n_steps=warmup)
         else:
             _lib.check(_lib.lib().dsd_plan(model._h, B, 2, H, W))
-        barrier()
-        t1 = time.time()
-        self.x = run_device_loop(model, sched, self.x, cond, seed=1234, first_step=warmup, n_steps=steps)
-        barrier()
-        dt = time.time() - t1
-        ms, per_rank = reduce_max(dt / steps * 1e3)
+        ev_reps, wall_reps, first = [], [], warmup
+        for _ in range(max(1, repeats)):
+            if first + steps > sched.steps:
+                first = warmup                     # every step of the chain runs the same kernels on the same shapes
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            barrier()
+            t1 = time.time()
+            e0.record()
+            self.x = run_device_loop(model, sched, self.x, cond, seed=1234, first_step=first, n_steps=steps)
+            e1.record()
+            barrier()
+            dt = time.time() - t1
+            ev_reps.append(reduce_max(e0.elapsed_time(e1) / steps))
+            wall_reps.append(reduce_max(dt / steps * 1e3))
+            first += steps
+        ms, per_rank = sorted(ev_reps, key=lambda r: r[0])[len(ev_reps) // 2]
         info = model.plan_info()
         res = {"precision": precision, "ms_per_step": round(ms, 3), "per_rank_ms_per_step": per_rank,
+               "timing": {"method": "hipEvents on the launch stream around K steps, between barrier + synchronize; max over ranks "
+                                    "per repeat, median over repeats", "repeats": len(ev_reps),
+                          "ms_per_step_repeats": [round(r[0], 3) for r in ev_reps],
+                          "ms_per_step_min": round(min(r[0] for r in ev_reps), 3), "ms_per_step_max": round(max(r[0] for r in ev_reps), 3),
+                          "host_clock_ms_per_step_repeats": [round(r[0], 3) for r in wall_reps]},
                "value": round((B * self.world) / (1000.0 * ms / 1e3), 6),
                "whole_step_tflops": round(info["flops"] / (ms / 1e3) / 1e12, 2), "finite": bool(torch.isfinite(self.x).all()),
                "info": info, "roofline": None, "kernels": None}
@@ -432,7 +522,17 @@ def run_rank(args):
         vals = [float(v.item()) for v in allr]
         return max(vals), [round(v, 3) for v in vals]
 
-    main_res = leg.measure(args.precision, args.steps, args.warmup, 0 if args.no_profile else 2, barrier, reduce_max)
+    main_res = leg.measure(args.precision, args.steps, args.warmup, 0 if args.no_profile else 2, barrier, reduce_max,
+                           repeats=args.repeats)
+    # per-rank device footprint (slab + arena + weight pieces + scratch, dsd_device_bytes): no rank may hold a second copy
+    dev_bytes = [main_res["info"].get("device_bytes", 0)]
+    if world > 1:
+        mine = torch.tensor([float(dev_bytes[0])], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        dev_bytes = [int(v.item()) for v in allr]
+        if not stub:
+            assert max(dev_bytes) - min(dev_bytes) <= 0.01 * max(dev_bytes), f"ranks differ in device footprint: {dev_bytes}"
     ms_per_step, slices_per_s = main_res["ms_per_step"], main_res["value"]
     info, finite, roofline, kernels = main_res["info"], main_res["finite"], main_res["roofline"], main_res["kernels"]
 
@@ -449,6 +549,7 @@ def run_rank(args):
             assert [float(p.flatten()[0]) for p in parts] == [float(r) for r in range(world)]
     rccl_ranks = dist.get_world_size() if world > 1 else 1
 
+    workloads = None
     modes, samplers, cpu, rel = {args.precision: {k: main_res[k] for k in ("ms_per_step", "value", "whole_step_tflops")}}, None, None, None
     if not stub and world == 1:
         from diffusion_models_dsdiff_amd import _lib
@@ -505,6 +606,17 @@ def run_rank(args):
                 "ms_per_evaluation": round(dt / 20 * 1e3, 2), "finite": bool(torch.isfinite(y).all()),
                 "note": "logSNR spacing, order 2, dynamic thresholding (radix-select quantile) — a different sampler, not the "
                         "1000-step metric"}}
+        if not args.no_workloads and headline_args(args):
+            # BASELINE configs[2..4], each with its own roofline block (tools/workloads.py); never part of `value`
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import workloads as WL
+            workloads = {}
+            try:
+                model.set_precision(args.precision)
+                workloads["brats_ddim50"] = WL.brats_ddim(model, B, H, W, leg.mp.get("parameterization", "eps"))
+                _lib.check(_lib.lib().dsd_plan(model._h, B, 2, H, W))
+            except Exception as e:          # a side line must never take the headline down
+                workloads["brats_ddim50"] = {"error": repr(e)}
         if args.cpu_seconds > 0:
             # CPU leg: the oracle timed on this host AND used as the checker of the GPU path on the same input, same run
             sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
@@ -518,6 +630,18 @@ def run_rank(args):
                            "adds the last steps of the 1000-step chain and a row of a batch-16 forward"}
             _lib.check(_lib.lib().dsd_plan(model._h, B, 2, H, W))
 
+    if workloads is not None:
+        # the other networks need the device memory the 981.5 M model holds (slab + pieces + 26 GiB arena): run them last
+        del model
+        leg.model = None
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        for key, fn in (("latent", lambda: WL.latent_path(args.batch)), ("dit_b8_512", lambda: WL.dit_step(args.batch, "f16"))):
+            try:
+                workloads[key] = fn()
+            except Exception as e:
+                workloads[key] = {"error": repr(e)}
     if rank == 0:
         B, H, W = args.batch, args.size, args.size
         headline = (B == HEADLINE["batch"] and H == HEADLINE["size"] and args.model_channels is None and not stub
@@ -548,10 +672,13 @@ def run_rank(args):
             "cpu_baseline": cpu,
             "rccl_ranks": rccl_ranks,
             "per_rank_ms_per_step": main_res["per_rank_ms_per_step"],
+            "per_rank_device_bytes": dev_bytes,
+            "timing": main_res.get("timing"),
             "gather_ms": None if gather_ms is None else round(gather_ms, 3),
             "kernels": kernels,
             "modes": modes,
             "samplers": samplers,
+            "workloads": workloads,
             "extra": {"gpu": leg.gpu_name, "compute_units": leg.n_cu, "finite_output": finite,
                       "workspace_GiB": round(info["workspace_bytes"] / 2 ** 30, 2), "launches_per_step": info["launches"],
                       "executed_flops_per_step": info["flops"],
@@ -561,7 +688,8 @@ def run_rank(args):
                                      ("torch.distributed.run" if world > 1 else "single process"),
                       "backend": backend if world > 1 else None,
                       "seconds_per_1000_step_batch": round(ms_per_step, 3),
-                      "setup_s": round(leg.t_setup, 1), "weight_broadcast_ms": leg.bcast_ms},
+                      "setup_s": round(leg.t_setup, 1), "weight_broadcast_ms": leg.bcast_ms,
+                      "weight_broadcast_buckets": getattr(leg, "bcast_buckets", None)},
         }
         if not headline:
             out["valid_for_baseline"] = False

@@ -35,6 +35,7 @@ def _is_zero_init(name: str) -> bool:
 class NativeModule(nn.Module):
     """An nn.Module whose parameters mirror a libdsdiff handle's parameter table."""
 
+    _skip_init = False     # parallel.empty_init(): parameter storage is allocated but not initialised (values arrive by broadcast)
     _zero_sites = True     # apply the reference's zero_module() initialisation sites (U-Net blocks); the VAE has none
     _strip = ""            # prefix of the C-side parameter names that this module's own tree does not carry
 
@@ -43,6 +44,7 @@ class NativeModule(nn.Module):
         self._h = C.c_void_p()
         self._uploaded: Dict[str, tuple] = {}
         self._cname: Dict[str, str] = {}      # python parameter name -> name in the library's table
+        self._remote: set = set()              # parameters whose values live in the library only (upload_param)
         self._device_index = 0
 
     # ---- parameter tree from the C-side table (names identical to the reference state_dict)
@@ -60,7 +62,9 @@ class NativeModule(nn.Module):
             p = nn.Parameter(torch.empty(shp, dtype=torch.float32), requires_grad=False)
             base = nm.rsplit(".", 1)[0]
             with torch.no_grad():
-                if self._zero_sites and _is_zero_init(nm):
+                if NativeModule._skip_init:
+                    pass
+                elif self._zero_sites and _is_zero_init(nm):
                     p.zero_()
                 elif len(shp) >= 2:                      # nn.Conv*/nn.Linear default: kaiming_uniform(a=sqrt(5))
                     fi = int(torch.tensor(shp[1:]).prod())
@@ -141,9 +145,12 @@ class NativeModule(nn.Module):
         return (0, numel // 2, numel - 1) if numel > 0 else ()
 
     def _fingerprints(self):
+        return self._fingerprints_of(self.named_parameters())
+
+    def _fingerprints_of(self, named):
         """{name: (v0, v_mid, v_last)}; CPU parameters are read through their address, CUDA ones with one gather."""
         out, cuda = {}, []
-        for nm, p in self.named_parameters():
+        for nm, p in named:
             n = p.numel()
             if n == 0:
                 out[nm] = ()
@@ -158,6 +165,21 @@ class NativeModule(nn.Module):
                 out[nm] = tuple(float(x) for x in v)
         return out
 
+    def upload_param(self, nm: str, t: torch.Tensor):
+        """Upload ONE parameter from `t` (any device) into the library without touching the module's own storage, and
+        remember the module-side state as uploaded — the receiving end of parallel.broadcast_params_bucketed: on ranks
+        other than the source the torch-side tensors stay uninitialised, the library holds the values."""
+        p = dict(self.named_parameters())[nm]
+        assert tuple(t.shape) == tuple(p.shape), (nm, tuple(t.shape), tuple(p.shape))
+        t = t.detach().float().contiguous()
+        shp = (C.c_int64 * max(1, t.dim()))(*t.shape)
+        check(lib().dsd_set_param(self._h, self._cname.get(nm, nm).encode(), C.c_void_p(t.data_ptr()), shp, t.dim(), int(t.is_cuda),
+                                  stream_ptr() if t.is_cuda else None))
+        # the module-side storage may be uninitialised memory (parallel.empty_init): it is identified by pointer + version
+        # only, never by its values
+        self._uploaded[nm] = (p.data_ptr(), p._version, p.device.type, "remote")
+        self._remote.add(nm)
+
     def mark_dirty(self, names=None):
         """Force the next sync_params() to re-upload `names` (default: every parameter)."""
         for nm in (list(self._uploaded) if names is None else names):
@@ -168,8 +190,13 @@ class NativeModule(nn.Module):
         (version counter) and in-place edits through ``.data`` (value fingerprint, see above).  ``force=True`` re-uploads
         everything unconditionally."""
         L = lib()
-        fps = self._fingerprints()
+        fps = self._fingerprints_of([(nm, p) for nm, p in self.named_parameters() if nm not in self._remote])
         for nm, p in self.named_parameters():
+            if nm in self._remote:
+                if self._uploaded.get(nm) == (p.data_ptr(), p._version, p.device.type, "remote"):
+                    continue                   # (also under force: the module-side storage holds no values to upload)
+                self._remote.discard(nm)       # the module-side tensor was written after all: it is the truth again
+                fps.update(self._fingerprints_of([(nm, p)]))
             key = (p.data_ptr(), p._version, p.device.type, fps[nm])
             if not force and self._uploaded.get(nm) == key:
                 continue

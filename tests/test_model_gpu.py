@@ -311,6 +311,55 @@ def test_full_size_vs_oracle(full_model):
     assert err < 1e-4
 
 
+def test_full_size_four_streams_vs_oracle(full_model):
+    """BASELINE configs[2] at full size: the BraTS branch x.shape[1] == 4 (UNet_DS_Diff/model.py:659-663)
+    gives the al / l encoder streams LIVE inputs, so all four streams run the 256-row / NT = 5 / tap-reuse + GroupNorm kernels
+    on real data — launch shapes the 2-channel tests never exercise (there those two streams see one shared zero plane).
+      (a) row 11 of a BATCH-16 forward with 4 input channels, a different timestep per row, vs the oracle's batch-1 forward
+          of that row: <= 1e-5 (bf16x6, the default);
+      (b) the last 3 steps of the 50-step DDIM chain the BraTS trainer configures (timestep_respacing "50",
+          rescale_timesteps=True -> float timesteps, eta 0; gaussian_diffusion.py:618-665, respace.py:123-128) at 256x256,
+          three conditioning channels: <= 1e-4 on the fp32 image.
+    4 oracle forwards at 256x256."""
+    from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
+    from diffusion_models_dsdiff_amd._sched import run_device_loop
+    from oracle import samplers as OS
+    m, cfg, sd = full_model
+    m.set_precision("bf16x6")
+    row = 11
+    x16 = randn((16, 4, 256, 256), 181)
+    t16 = (torch.arange(16) * 59 + 13) % 1000
+    yo = O.unet_forward(cfg, sd, x16[row:row + 1], t16[row:row + 1])[0]
+    assert float(yo.abs().max()) > 1e-3
+    y16 = m._run(x16.cuda(), t16.cuda(), want_feats=False)[0]
+    e16 = rel_l2(y16[row:row + 1], yo)
+    print(f"full-size forward 256x256, 4 input channels: row {row} of batch 16 rel-L2 {e16:.3e}")
+    assert e16 < 1e-5 and bool(torch.isfinite(y16).all())
+    # the 2-channel branch must NOT give the same answer for these inputs (the al / l streams really are live)
+    assert rel_l2(m._run(x16[row:row + 1, :2].cuda(), t16[row:row + 1].cuda(), want_feats=False)[0], yo) > 1e-3
+    # (b) last 3 steps of the 50-step DDIM chain, 3 conditions
+    shape, n = (1, 1, 256, 256), 3
+    cond3, x_start = cond_image_((1, 3, 256, 256), 182), randn(shape, 183)
+    z = torch.zeros((50,) + shape)                        # eta = 0: the noise takes no part
+    d = create_gaussian_diffusion(steps=1000, timestep_respacing="50", rescale_timesteps=True, parameterization="v")
+    sched = d._schedule(True, 0.0, True)
+    y = run_device_loop(m, sched, x_start.cuda(), cond3.cuda(), step_noise=z.cuda(), first_step=50 - n, n_steps=n)
+    od = OS.DiffusionA(steps=1000, timestep_respacing="50", rescale_timesteps=True, parameterization="v")
+    model = lambda xx, tt: O.unet_forward(cfg, sd, xx, tt)[0]
+    T = od.tab
+    img = x_start
+    for k in range(50 - n, 50):                           # DiffusionA.ddim_sample_loop, iterations k = 47, 48, 49 (t = 2, 1, 0)
+        t = torch.tensor([49 - k])
+        _, _, x0 = od.p_mean_variance(model, img, t, True, [cond3])
+        ext = lambda a: torch.from_numpy(a)[t].float().view(-1, 1, 1, 1)
+        eps = (ext(T["sqrt_recip_alphas_cumprod"]) * img - x0) / ext(T["sqrt_recipm1_alphas_cumprod"])
+        abp = ext(T["alphas_cumprod_prev"])
+        img = x0 * torch.sqrt(abp) + torch.sqrt(1 - abp) * eps
+    err = rel_l2(y, img)
+    print(f"full-size last-{n}-steps 50-step DDIM chain (rescaled float timesteps), 3 conditions, 256x256: rel-L2 {err:.3e}")
+    assert err < 1e-4
+
+
 def test_winograd_mode_full_size_vs_oracle(full_model):
     """dsd_set_winograd (opt-in, bf16x6): the large 3x3 layers on the F(2,3)-along-W kernel.  At 256x256 every layer down to
     128x128 takes it at batch 2 (>= 512 workgroups); the network output must hold the same 1e-5 against the oracle as the direct kernels, the
