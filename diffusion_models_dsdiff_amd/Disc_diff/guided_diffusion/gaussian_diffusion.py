@@ -136,12 +136,18 @@ class GaussianDiffusion:
     # ------------------------------------------------------------------ loops
     def _loop(self, ddim, model, shape, noise, clip_denoised, denoised_fn, cond_fn, model_kwargs, device, progress,
               eta=0.0, step_noise=None, seed=None):
-        if denoised_fn is not None or cond_fn is not None:
-            raise NotImplementedError("denoised_fn / cond_fn hooks are not supported by the device loop")
         assert isinstance(shape, (tuple, list))
         model_kwargs = model_kwargs or {}
         sched = self._schedule(ddim, eta, clip_denoised)
+        hooks = denoised_fn is not None or cond_fn is not None
+        self._check_hooks(ddim, denoised_fn, cond_fn)
         unet = find_unet(model)
+        if hooks and unet is not None:
+            # a Python hook sits between network and update: per-step host loop; a bare native U-Net does not concatenate
+            # c_concat itself (DiffusionWrapper.forward does, ddpm.py:1328-1333)
+            if unet is model:
+                model = lambda x, t, _u=unet, **kw: _u(th.cat([x] + [c.to(x.device) for c in kw.get("c_concat", [])], 1), t)
+            unet = None
         if device is None:
             device = next(model.parameters()).device if hasattr(model, "parameters") else th.device("cuda")
             if th.device(device).type != "cuda":
@@ -165,8 +171,60 @@ class GaussianDiffusion:
             out = model(x, t, **model_kwargs)
             if isinstance(out, tuple):
                 out = out[0]
-            sampler_update(sched, k, out, x, None if step_noise is None else step_noise[k].to(device), seed)
+            self._hooked_update(sched, k, out, x, t, None if step_noise is None else step_noise[k].to(device), seed,
+                                denoised_fn, cond_fn, model_kwargs)
         return x
+
+    # ---- denoised_fn / cond_fn (:312-313, :386-398, :460-463)
+    def _check_hooks(self, ddim, denoised_fn, cond_fn):
+        if cond_fn is None:
+            return
+        if ddim:
+            raise NotImplementedError(
+                "cond_fn with DDIM (condition_score, gaussian_diffusion.py:400-420) is not built: it re-derives pred_xstart from a "
+                "shifted eps WITHOUT clipping it again, which the fused update cannot express.  Use p_sample_loop(..., cond_fn=...) "
+                "(classifier guidance on the DDPM mean, supported for the fixed variance types), or write the step loop over "
+                "model(x, t) and _sched.sampler_update() yourself")
+        if self.model_var_type == ModelVarType.LEARNED_RANGE:
+            raise NotImplementedError(
+                "cond_fn needs the per-pixel variance of the step; with learn_sigma it lives inside the fused update.  Use a "
+                "fixed-variance diffusion (learn_sigma=False) with p_sample_loop(..., cond_fn=...)")
+
+    def _hooked_update(self, sched, k, out, x, t, noise, seed, denoised_fn, cond_fn, model_kwargs, want_x0=False):
+        """One update with the reference's hooks, still on the fused HIP kernel.
+        denoised_fn acts on the predicted x_start BEFORE the clip (process_xstart :311-316): x_start is formed here from the
+        network output with the reference's fp32 expressions, handed to denoised_fn, and the kernel is then run in its
+        x_start-prediction mode (it clips and does the rest).  cond_fn shifts the mean by variance * gradient (:386-398);
+        the sample is linear in the mean, so the shift is added to the kernel's result."""
+        if denoised_fn is None and cond_fn is None:
+            return sampler_update(sched, k, out, x, noise, seed, want_x0=want_x0)
+        grad = None
+        if cond_fn is not None:
+            grad = cond_fn(x, t, **model_kwargs).float()              # x is still x_t here; t as the network received it
+        run = sched
+        if denoised_fn is not None:
+            c = th.from_numpy(sched.coef[k]).to(x.device)
+            xs = x.shape
+            C = xs[1]
+            eps_or_v, rest = (out[:, :C], out[:, C:]) if sched.c.learned_range else (out, None)
+            if sched.c.pred == _lib.PRED_V:                            # predict_start_from_z_and_v :236-242
+                x0 = c[0] * x - c[1] * eps_or_v
+            elif sched.c.pred == _lib.PRED_EPS:                        # _predict_xstart_from_eps :352-357
+                x0 = c[2] * x - c[3] * eps_or_v
+            else:
+                x0 = eps_or_v
+            x0 = denoised_fn(x0).float()
+            out = x0 if rest is None else th.cat([x0, rest], 1)
+            run = sched.with_pred(_lib.PRED_X0)
+        x0_out = sampler_update(run, k, out, x, noise, seed, want_x0=want_x0)
+        if grad is not None:
+            # p_mean_var["variance"] of this step (:296-309): the variance TABLE (FIXED_SMALL pairs the raw posterior variance,
+            # 0 at t = 0, with the clipped log), gathered in float64 and rounded to fp32 as _extract_into_tensor does
+            i = self.num_timesteps - 1 - k
+            var = (np.append(self.posterior_variance[1], self.betas[1:]) if self.model_var_type == ModelVarType.FIXED_LARGE
+                   else self.posterior_variance)
+            x.add_(float(np.float32(var[i])) * grad)
+        return x0_out
 
     def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                       model_kwargs=None, device=None, progress=False, step_noise=None, seed=None):
@@ -201,9 +259,10 @@ class GaussianDiffusion:
                                  skip_type="logSNR", method="multistep", lower_order_final=False,
                                  denoise_to_zero=denoise, solver_type="dpmsolver")
 
-    def _progressive(self, ddim, model, shape, noise, clip_denoised, model_kwargs, device, eta):
+    def _progressive(self, ddim, model, shape, noise, clip_denoised, model_kwargs, device, eta, denoised_fn=None, cond_fn=None):
         model_kwargs = model_kwargs or {}
         sched = self._schedule(ddim, eta, clip_denoised)
+        self._check_hooks(ddim, denoised_fn, cond_fn)
         if device is None:
             device = th.device("cuda")
         img = (noise if noise is not None else th.randn(*shape, device=device)).to(device).float().contiguous().clone()
@@ -213,26 +272,29 @@ class GaussianDiffusion:
             i = self.num_timesteps - 1 - k
             t = th.tensor([i] * B, device=device)
             out = self._call_model(model, img, t, model_kwargs)
-            x0 = sampler_update(sched, k, out, img, None, seed, want_x0=True)
+            x0 = self._hooked_update(sched, k, out, img, self._model_t(t), None, seed, denoised_fn, cond_fn, model_kwargs, want_x0=True)
             yield {"sample": img.clone(), "pred_xstart": x0}
 
     def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None,
                                   model_kwargs=None, device=None, progress=False):
         """:569-616 (yields {"sample","pred_xstart"} per step)."""
-        assert denoised_fn is None and cond_fn is None
-        yield from self._progressive(False, model, shape, noise, clip_denoised, model_kwargs, device, 0.0)
+        yield from self._progressive(False, model, shape, noise, clip_denoised, model_kwargs, device, 0.0, denoised_fn, cond_fn)
 
     def ddim_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
                                      cond_fn=None, model_kwargs=None, device=None, progress=False, eta=0.0):
         """:739-786."""
-        assert denoised_fn is None and cond_fn is None
-        yield from self._progressive(True, model, shape, noise, clip_denoised, model_kwargs, device, eta)
+        yield from self._progressive(True, model, shape, noise, clip_denoised, model_kwargs, device, eta, denoised_fn, cond_fn)
 
     # ------------------------------------------------------------------ single steps
     def _scale_timesteps(self, t):
         if self.rescale_timesteps:
             return t.float() * (1000.0 / self.num_timesteps)
         return t
+
+    def _model_t(self, t):
+        """loop index -> the timestep the network (and cond_fn) receives (respace.py:123-128)."""
+        tv = th.from_numpy(self._model_timestep_values()).to(t.device)[t]
+        return tv if self.rescale_timesteps else tv.long()
 
     def _call_model(self, model, x, t, model_kwargs):
         """p_mean_variance's network call (:266-278): loop index -> network timestep, tuple -> tensor."""
@@ -242,25 +304,25 @@ class GaussianDiffusion:
         out = model(x, tv, **model_kwargs)
         return out[0] if isinstance(out, tuple) else out
 
-    def _single(self, ddim, model, x, t, clip_denoised, model_kwargs, eta):
+    def _single(self, ddim, model, x, t, clip_denoised, model_kwargs, eta, denoised_fn=None, cond_fn=None):
         model_kwargs = model_kwargs or {}
         i = int(t[0])
         assert bool((t == i).all()), "all samples of a batch share the timestep in every reference loop"
         sched = self._schedule(ddim, eta, clip_denoised)
+        self._check_hooks(ddim, denoised_fn, cond_fn)
         out = self._call_model(model, x, t, model_kwargs)
         xn = x.float().contiguous().clone()
-        x0 = sampler_update(sched, self.num_timesteps - 1 - i, out, xn, None, _seed_from_torch(), want_x0=True)
+        x0 = self._hooked_update(sched, self.num_timesteps - 1 - i, out, xn, self._model_t(t.to(x.device)), None, _seed_from_torch(),
+                                 denoised_fn, cond_fn, model_kwargs, want_x0=True)
         return {"sample": xn, "pred_xstart": x0}
 
     def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None):
         """:422-465."""
-        assert denoised_fn is None and cond_fn is None
-        return self._single(False, model, x, t, clip_denoised, model_kwargs, 0.0)
+        return self._single(False, model, x, t, clip_denoised, model_kwargs, 0.0, denoised_fn, cond_fn)
 
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, eta=0.0):
         """:618-665."""
-        assert denoised_fn is None and cond_fn is None
-        return self._single(True, model, x, t, clip_denoised, model_kwargs, eta)
+        return self._single(True, model, x, t, clip_denoised, model_kwargs, eta, denoised_fn, cond_fn)
 
 
 def _extract_into_tensor(arr, timesteps, broadcast_shape):

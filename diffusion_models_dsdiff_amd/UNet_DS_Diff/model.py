@@ -135,11 +135,17 @@ class NativeModule(nn.Module):
         return {v: k for k, v in _lib.PRECISIONS.items()}[code]
 
     # ---- change detection ---------------------------------------------------------------------------
-    # (data_ptr, _version, device) catches load_state_dict, .to(), optimiser steps and every in-place op on the parameter
-    # itself.  Edits through ``p.data`` (``p.data.copy_(ema)``, ``p.data.normal_()`` — the idiom of the reference's
-    # LitEma.copy_to / ema_scope weight swaps, ldm/modules/ema.py) bump neither, so a sparse value fingerprint (three
-    # elements per parameter) is compared as well: a swap or re-initialisation changes every element, so it cannot hide
-    # from it.  An edit that leaves those three elements untouched needs mark_dirty() / sync_params(force=True).
+    # The contract: (data_ptr, _version, device) is compared on every forward — it catches load_state_dict, .to(), optimiser
+    # steps and every in-place op on the parameter itself, and costs no device work.  Edits through ``p.data``
+    # (``p.data.copy_(ema)``, ``p.data.normal_()`` — the idiom of the reference's LitEma.copy_to / ema_scope weight swaps,
+    # ldm/modules/ema.py) bump neither, so they must be announced with mark_dirty() / sync_params(force=True).
+    # As a safety net for HOST-resident parameters a sparse value fingerprint (three elements per parameter, read through
+    # their address: no tensor op) is compared as well while ``detect_data_edits`` is True (default): a swap or
+    # re-initialisation changes every element and cannot hide from it; an edit that leaves those three elements untouched
+    # (a masked / sliced write) is NOT seen — the contract above stands.  CUDA-resident parameters are never
+    # fingerprinted: reading them back is a device synchronisation on every forward.
+    detect_data_edits = True
+
     @staticmethod
     def _probe_index(numel):
         return (0, numel // 2, numel - 1) if numel > 0 else ()
@@ -148,21 +154,16 @@ class NativeModule(nn.Module):
         return self._fingerprints_of(self.named_parameters())
 
     def _fingerprints_of(self, named):
-        """{name: (v0, v_mid, v_last)}; CPU parameters are read through their address, CUDA ones with one gather."""
-        out, cuda = {}, []
+        """{name: (v0, v_mid, v_last)} for host-resident fp32 parameters (read through their address), () for everything else
+        (CUDA-resident parameters, or detect_data_edits switched off)."""
+        out = {}
         for nm, p in named:
             n = p.numel()
-            if n == 0:
-                out[nm] = ()
-            elif p.device.type == "cpu" and p.dtype == torch.float32 and p.is_contiguous():
+            if self.detect_data_edits and n and p.device.type == "cpu" and p.dtype == torch.float32 and p.is_contiguous():
                 base = p.data_ptr()
                 out[nm] = tuple(C.c_float.from_address(base + 4 * i).value for i in self._probe_index(n))
             else:
-                cuda.append((nm, p))
-        if cuda:
-            vals = torch.stack([p.detach().reshape(-1)[list(self._probe_index(p.numel()))].float() for _, p in cuda]).cpu()
-            for (nm, _), v in zip(cuda, vals):
-                out[nm] = tuple(float(x) for x in v)
+                out[nm] = ()
         return out
 
     def upload_param(self, nm: str, t: torch.Tensor):
@@ -187,8 +188,8 @@ class NativeModule(nn.Module):
 
     def sync_params(self, force: bool = False):
         """Upload parameters that changed since the last upload: load_state_dict, .to(), in-place ops on the parameter
-        (version counter) and in-place edits through ``.data`` (value fingerprint, see above).  ``force=True`` re-uploads
-        everything unconditionally."""
+        (version counter); whole-tensor ``.data`` rewrites of host parameters are caught by the fingerprint safety net, any
+        other ``.data`` edit needs mark_dirty() first (see above).  ``force=True`` re-uploads everything unconditionally."""
         L = lib()
         fps = self._fingerprints_of([(nm, p) for nm, p in self.named_parameters() if nm not in self._remote])
         for nm, p in self.named_parameters():

@@ -31,6 +31,12 @@ class Schedule:
     def steps(self) -> int:
         return int(self.c.steps)
 
+    def with_pred(self, pred: int) -> "Schedule":
+        """The same schedule for a network output of another kind (DSD_PRED_*): the denoised_fn hook hands the update kernel
+        an x_start it has already formed and post-processed."""
+        return Schedule(int(self.c.mode), int(pred), self.coef, self.t_model, self.nonzero, bool(self.c.learned_range),
+                        bool(self.c.clip_denoised), float(self.c.eta))
+
 
 def find_unet(model):
     """Locate the native DSUnetModel behind the object the reference passes as ``model``

@@ -629,11 +629,11 @@ int dsd_bench_conv2d_stamps(int N, int H, int W, int Cin, int Cout, int warm, in
 
 int dsd_bench_mfma_peak(int variant, int workgroups_per_cu, float ms_target, int iters, float* avg_ms, double* tflops) {
     DSD_TRY
-    DSD_CHECK(variant >= 0 && variant <= 3 && iters >= 1 && avg_ms && tflops, "bad argument");
+    DSD_CHECK(variant >= 0 && variant <= 7 && iters >= 1 && avg_ms && tflops, "bad argument");
     hipStream_t s = nullptr;
     const int wgs = 256 * (workgroups_per_cu > 0 ? std::min(workgroups_per_cu, 64) : 8);
     Tmp src((size_t)mfma_peak_src_bytes()), sink((size_t)wgs * 256 * sizeof(float));
-    mfma_peak_fill(src.p, variant >= 2, s);
+    mfma_peak_fill(src.p, (variant & 2) != 0, s);
     hipEvent_t e0, e1;
     DSD_HIP(hipEventCreate(&e0));
     DSD_HIP(hipEventCreate(&e1));

@@ -520,6 +520,11 @@ void dsd::net_set_param(dsd_handle* h, const char* name, const float* src, const
     float* dst = reinterpret_cast<float*>(h->slab + p.off);
     const size_t bytes = (size_t)p.numel * sizeof(float);
     const hipMemcpyKind kind = src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    // the repack staging buffer is shared by every upload: an upload on ANOTHER stream than the previous one first waits for it
+    if (h->any_param_upload && h->last_param_stream != s) {
+        auto pe = h->param_evs.find(h->last_param_stream);
+        if (pe != h->param_evs.end()) DSD_HIP(hipStreamWaitEvent(s, pe->second, 0));
+    }
     if (p.pack3x3) {
         if (h->staging_bytes < bytes) {
             if (h->staging) {
@@ -538,10 +543,15 @@ void dsd::net_set_param(dsd_handle* h, const char* name, const float* src, const
     }
     p.set = true;
     // plan-time consumers of the slab (weight splitting) may run on another stream: they wait on this event
-    if (!h->param_ev) DSD_HIP(hipEventCreateWithFlags(&h->param_ev, hipEventDisableTiming));
-    DSD_HIP(hipEventRecord(h->param_ev, s));
+    {
+        hipEvent_t& ev = h->param_evs[s];
+        if (!ev) DSD_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        DSD_HIP(hipEventRecord(ev, s));
+        h->last_param_stream = s;
+        h->any_param_upload = true;
+    }
     const std::string conv_name = p.name.size() > 7 ? p.name.substr(0, p.name.size() - 7) : p.name;   // "<conv>.weight" -> "<conv>"
-    for (const std::string& key : {conv_name, conv_name + "#f16", conv_name + "#wino"}) {
+    for (const std::string& key : {conv_name, conv_name + "#f16", conv_name + "#wino", p.name + "#h16", p.name + "#b16"}) {
         auto sp = h->wsplit.find(key);
         if (sp != h->wsplit.end()) {
             DSD_HIP(hipDeviceSynchronize());
@@ -606,7 +616,8 @@ void dsd::net_free(dsd_handle* h) {
     if (h->freqs) (void)hipFree(h->freqs);
     if (h->ovf) (void)hipFree(h->ovf);
     if (h->slice_ids) (void)hipFree(h->slice_ids);
-    if (h->param_ev) (void)hipEventDestroy(h->param_ev);
+    for (auto& kv : h->param_evs) (void)hipEventDestroy(kv.second);
+    h->param_evs.clear();
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
     for (auto& kv : h->wsplit) (void)hipFree(kv.second);
@@ -2024,12 +2035,21 @@ void dsd::net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int
     p.gen = gen;
     p.B = B; p.C = C; p.H = H; p.W = W; p.zero_al_l = zero_al_l; p.want_feats = want_feats;
     p.aux_len = aux_len; p.aux_len2 = aux_len2; p.share = share;
-    if (h->param_ev) DSD_HIP(hipStreamWaitEvent(s, h->param_ev, 0));   // uploads enqueued on any stream have landed first
+    for (auto& kv : h->param_evs) DSD_HIP(hipStreamWaitEvent(s, kv.second, 0));   // uploads enqueued on ANY stream have landed first
     Builder b(h, p, B, s);
-    if (h->is_block)
-        build_block(b, C, H, W, aux_len, aux_len2);
-    else
-        build_unet(b, H, W, zero_al_l != 0, want_feats != 0, share != 0);
+    try {
+        if (h->is_block)
+            build_block(b, C, H, W, aux_len, aux_len2);
+        else
+            build_unet(b, H, W, zero_al_l != 0, want_feats != 0, share != 0);
+    } catch (...) {
+        // a plan that fails half-way may have enqueued weight-piece kernels on s: let them finish before anybody can free or
+        // overwrite what they read, and leave no half-built plan behind
+        if (b.split_any) (void)hipStreamSynchronize(s);
+        p = Plan{};
+        p.gen = gen;
+        throw;
+    }
     p.arena_bytes = b.ar.peak + 256;
     if (p.arena_bytes > h->arena_cap) {
         DSD_HIP(hipDeviceSynchronize());

@@ -136,7 +136,12 @@ struct dsd_handle {
     int n_slice_ids = 0;
     // whole-forward hipGraph (sampling loops): captured on cap_stream after the first host-launched forward of a plan,
     // replayed on the caller's stream while plan + bound pointers stay the same
-    hipEvent_t param_ev = nullptr;   // recorded after every dsd_set_param on the stream it used
+    // one event per stream dsd_set_param has been called on, re-recorded after every upload on that stream: plan-time
+    // consumers of the slab (weight splitting, on the planning call's stream) wait on ALL of them, so uploads spread over
+    // several non-blocking streams need no synchronisation by the caller
+    std::unordered_map<hipStream_t, hipEvent_t> param_evs;
+    hipStream_t last_param_stream = nullptr;
+    bool any_param_upload = false;
     int use_graph = 0;
     int use_winograd = 0;    // bf16x6 only, opt-in: 3x3 stride-1 convolutions as F(2,3) along the width (conv_wino.hip)
     int fuse_gn_stats = 1;   // GroupNorm statistics from the producing kernel's epilogue (0: always the standalone pass)

@@ -17,7 +17,11 @@ What the reference does around ``sample_fn`` and what is rebuilt here:
   * the two scikit-image metrics behind ``psnr`` / ``ssim`` (test_metrics.py:7-8,227-246,378-400): ``peak_signal_noise_ratio``,
     ``structural_similarity`` restated from scikit-image 0.18 and PINNED by values real scikit-image computed
     (tests/golden/metrics.npz, generator tests/golden/gen_metrics.py).
-Not rebuilt: multi-scale SSIM (torchmetrics), CW-SSIM (pyssim), FID / LPIPS (network weights), ANTs similarity, mutual information.
+  * the "ssim" the metric pass actually reports — torchmetrics' MS-SSIM per axial slice (test_metrics.py:249-274) — restated
+    from its published definition (``multiscale_structural_similarity``, ``ssim_torch``; parity unpinned: torchmetrics is
+    absent), and the per-id table + mean row of inference/get_metric_BraTs.py:54-126 (``metric_table``, written as CSV).
+Not rebuilt: CW-SSIM (pyssim), FID / LPIPS (network weights), ANTs similarity / Mattes mutual information (the table's ``mi``
+column holds NaN).
 
 PARITY UNPINNED for the array metrics and the slice bookkeeping: inference/test_metrics.py and the trainers do not import
 here (ants, lpips, SimpleITK, Lightning), and the reference holds no fixtures for these functions; tests/test_host_io.py checks
@@ -84,7 +88,11 @@ def find_slice_files(root: str) -> list:
         for fn in os.listdir(d):
             if fn.endswith(".h5"):
                 path = os.path.join(d, fn)
-                found.append((id_, parse_slice_path(path)[1], path))
+                try:
+                    found.append((id_, parse_slice_path(path)[1], path))
+                except ValueError:      # stats.h5, a MATLAB export, ...: not a <name>_<slice>.h5 slice file
+                    import warnings
+                    warnings.warn(f"{path}: name does not end in _<slice index>; skipped")
     found.sort()
     return [f[2] for f in found]
 
@@ -129,7 +137,11 @@ def read_nifti(path: str):
     n = int(np.prod(shape))
     arr = np.frombuffer(raw, dtype=dt, count=n, offset=max(vox_offset, 352)).reshape(shape[::-1])   # file order: x fastest
     arr = arr.astype(dt.newbyteorder("="))
-    if slope not in (0.0, 1.0) or (slope != 0.0 and inter != 0.0):
+    while arr.ndim > 3 and arr.shape[0] == 1:        # dim[0] = 4 with a trailing unit time axis: still a 3-D volume
+        arr = arr[0]
+    # scl_slope = 0 (or a non-finite value: some writers leave NaN there) means "no scaling" per the NIfTI-1 specification
+    scaled = np.isfinite(slope) and slope != 0.0 and np.isfinite(inter) and not (slope == 1.0 and inter == 0.0)
+    if scaled:
         arr = arr.astype(np.float32) * np.float32(slope) + np.float32(inter)
     return arr, bytes(hdr)
 
@@ -253,6 +265,105 @@ def ssim(true_array, pred_array, mask=None):
         t, p = t[sl], p[sl]
     t, p = scale12bit(t), scale12bit(p)
     return structural_similarity(t, p, win_size=9, data_range=t.max() - t.min())
+
+
+def _gauss1d(size, sigma):
+    d = np.arange((1 - size) / 2, (1 + size) / 2, 1.0, dtype=np.float64)
+    g = np.exp(-((d / sigma) ** 2) / 2)
+    return g / g.sum()
+
+
+def multiscale_structural_similarity(preds, target, data_range=None, kernel_size=11, sigma=1.5, k1=0.01, k2=0.03,
+                                     betas=(0.0448, 0.2856, 0.3001, 0.2363, 0.1333)):
+    """MS-SSIM of ONE 2-D image pair (Wang, Simoncelli, Bovik 2003), the form torchmetrics'
+    ``multiscale_structural_similarity_index_measure`` evaluates with its defaults — what the reference's metric pass
+    reports as "ssim" (inference/test_metrics.py:249-274): per scale a Gaussian window (11 taps, sigma 1.5, separable),
+    local means / biased (co)variances, luminance-contrast-structure map  (2 mx my + c1)(2 sxy + c2) / ((mx^2 + my^2 +
+    c1)(sx + sy + c2))  and contrast-structure map  (2 sxy + c2) / (sx + sy + c2), each averaged over the window-valid
+    interior and clamped at 0 ("relu" normalisation); 2x2 average pooling between the five scales; result
+    prod_{i<5} cs_i^beta_i * ssim_5^beta_5.  data_range None -> max(range(preds), range(target)); c = (k R)^2.
+    float64 throughout.  PARITY UNPINNED: torchmetrics is not installable here and the reference holds no value of it."""
+    from scipy.ndimage import correlate1d
+    x, y = np.asarray(preds, dtype=np.float64), np.asarray(target, dtype=np.float64)
+    if x.shape != y.shape or x.ndim != 2:
+        raise ValueError("expected two 2-D images of the same shape")
+    if min(x.shape) // 2 ** (len(betas) - 1) <= kernel_size - 1:
+        raise ValueError(f"image {x.shape} too small for {len(betas)} scales of an {kernel_size}-tap window")
+    R = float(max(x.max() - x.min(), y.max() - y.min())) if data_range is None else float(data_range)
+    c1, c2 = (k1 * R) ** 2, (k2 * R) ** 2
+    g = _gauss1d(kernel_size, sigma)
+    pad = (kernel_size - 1) // 2
+    blur = lambda a: correlate1d(correlate1d(a, g, axis=0, mode="mirror"), g, axis=1, mode="mirror")
+    vals = []
+    for i in range(len(betas)):
+        mx, my = blur(x), blur(y)
+        sxx, syy, sxy = blur(x * x) - mx * mx, blur(y * y) - my * my, blur(x * y) - mx * my
+        upper, lower = 2 * sxy + c2, sxx + syy + c2
+        full = ((2 * mx * my + c1) * upper) / ((mx * mx + my * my + c1) * lower)
+        inner = (slice(pad, -pad), slice(pad, -pad))
+        sim, cs = max(float(full[inner].mean()), 0.0), max(float((upper / lower)[inner].mean()), 0.0)
+        vals.append(sim if i == len(betas) - 1 else cs)
+        if i < len(betas) - 1:                                  # F.avg_pool2d(.., (2, 2)): trailing odd row / column dropped
+            h2, w2 = (x.shape[0] // 2) * 2, (x.shape[1] // 2) * 2
+            x = x[:h2, :w2].reshape(h2 // 2, 2, w2 // 2, 2).mean(axis=(1, 3))
+            y = y[:h2, :w2].reshape(h2 // 2, 2, w2 // 2, 2).mean(axis=(1, 3))
+    return float(np.prod(np.asarray(vals) ** np.asarray(betas, dtype=np.float64)))
+
+
+def ssim_torch(true_array, pred_array, mask=None):
+    """inference/test_metrics.py:249-274 — the "ssim" column of the reference's metric table: zero outside the mask, crop
+    to the mask's bounding box (exclusive upper bound, as the reference slices), 12-bit rescale of each volume, MS-SSIM of
+    every axial slice pair, averaged.  (The reference zeroes its INPUT arrays in place; copies are used here.)"""
+    m = _mask(true_array, mask)
+    t, p = np.where(m, true_array, 0), np.where(m, pred_array, 0)
+    nz = np.nonzero(m)
+    sl = tuple(slice(int(a.min()), int(a.max())) for a in nz)
+    t, p = scale12bit(t[sl]), scale12bit(p[sl])
+    return float(np.mean([multiscale_structural_similarity(p[i], t[i]) for i in range(t.shape[0])]))
+
+
+METRIC_COLUMNS = ["nrmse", "smape", "logac", "medsymac", "cc", "mi", "ssim", "lpips", "fid", "psnr"]
+
+
+def metric_row(gt_img, pred_img, mask_img=None):
+    """One row of inference/get_metric_BraTs.py:78-104 (without the id): the columns the reference fills with a constant 0
+    (cc, lpips, fid: their calls are commented out there) stay 0; ``mi`` is ANTs' Mattes mutual information in the
+    reference (test_metrics.py:77-90) — ANTs is not available and is not restated: the column holds NaN."""
+    gt_img, pred_img = np.asarray(gt_img, dtype=np.float64), np.asarray(pred_img, dtype=np.float64)
+    return [nrmse(gt_img, pred_img, mask_img), smape(gt_img, pred_img, mask_img), logac(gt_img, pred_img, mask_img),
+            medsymac(gt_img, pred_img, mask_img), 0.0, float("nan"), ssim_torch(gt_img, pred_img, mask_img), 0.0, 0.0,
+            psnr(gt_img, pred_img, mask_img)]
+
+
+def metric_table(pred_files, gt_dir, gt_name="ce.nii.gz", mask_name=None):
+    """get_metric_BraTs.py:54-115: for every prediction ``<id>_..._pred.nii.gz`` (id = text before the first '_') or
+    ``{id: path}`` entry, the ground truth ``<gt_dir>/<id>/<gt_name>`` (and, with mask_name, ``<gt_dir>/<id>/<mask_name>``
+    > 0 as mask); returns the table with the MEAN row first (float32 mean over the ids, as the reference computes it) and
+    the id rows after it: [["ids"] + METRIC_COLUMNS header not included]."""
+    if not isinstance(pred_files, dict):
+        pred_files = {os.path.basename(f).split(".")[0].split("_")[0]: f for f in pred_files if f.endswith(".nii.gz")}
+    rows = []
+    for id_, path in pred_files.items():
+        gt, _ = read_nifti(os.path.join(gt_dir, id_, gt_name))
+        pred, _ = read_nifti(path)
+        mask = None
+        if mask_name:
+            mask = read_nifti(os.path.join(gt_dir, id_, mask_name))[0] > 0
+        rows.append([str(id_)] + metric_row(gt, pred, mask))
+    if not rows:
+        return []
+    mean = np.mean(np.asarray([r[1:] for r in rows], dtype=np.float32), axis=0)
+    return [[0] + [float(v) for v in mean]] + rows
+
+
+def write_metric_csv(path, table):
+    """The sheet get_metric_BraTs.py:119-125 writes (header ids + the ten columns, mean row first), as CSV."""
+    import csv
+    with open(path, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["ids"] + METRIC_COLUMNS)
+        for r in table:
+            w.writerow(r)
 
 
 def psnr(true_array, pred_array, mask=None):

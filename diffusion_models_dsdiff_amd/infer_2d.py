@@ -7,8 +7,20 @@ Reads the SAME yaml keys (model yaml: ``model.params.{unet_config, parameterizat
 ``<dir>/<id>/<name>_<slice>.h5`` (preprocess/to_h5.py) and ``--input-keys`` naming the datasets used as condition channels
 (h5lite.py reads them; no h5py).  Either way they are taken as already scaled to [-1,1] and sized to a multiple of 32, which
 the reference does in its MONAI transform chain (not rebuilt).  Output: ``[N,1,H,W]`` as ``.npy``, or — with an h5 input
-and ``--output <dir>`` — one ``<dir>/<id>/pred.nii.gz`` volume per id, the slices stacked at their index as
-on_predict_end does (trainer_use_gaussian_diff.py:632-655; host_io.VolumeAssembler / write_nifti).
+and ``--output <dir>`` — one NIfTI volume per id, the slices stacked at their index as on_predict_end does
+(trainer_use_gaussian_diff.py:632-655; host_io.VolumeAssembler / write_nifti):
+  * ``--template-dir <dir>``: ``<dir>/<id>/<template-name>`` (default name: the last input key + ".nii.gz", as the trainer's
+    ``self.keys[-1] + ".nii.gz"``) is read, the prediction is ``zeros_like(template)`` with the predicted slices written at
+    their index (trailing unpredicted slices stay zero, dtype = the template's), and it is saved with the template's header
+    bytes (the role of ``pred_nii.CopyInformation(template_nii)``: spacing / origin / direction of the source volume).
+    Without a template the depth is ``max(slice) + 1``, float32, identity geometry.
+  * ``--task-id T``: files are named ``<output>/T_<id>_pred.nii.gz`` as the trainer names them (:649); otherwise
+    ``<output>/<id>/pred.nii.gz``.
+  * ``--gt-dir <dir>`` (+ ``--gt-name ce.nii.gz``, ``--mask-name``): the metric pass of inference/get_metric_BraTs.py:54-126
+    over the volumes just written — per-id rows + the mean row first — as ``<output>_metric.csv`` (the reference writes the
+    same table as .xlsx; its ``mi`` column is ANTs' Mattes MI, not restated: NaN).
+Remaining differences from the SimpleITK path: NIfTI headers are copied byte for byte, so the on-disk axis convention is
+the template's own (SimpleITK converts LPS <-> RAS when it writes); only single-file NIfTI-1 is handled.
 
 Sampler selection follows TryTrainerDiffusion.on_predict_start (trainers/trainer_use_gaussian_diff.py:586-600):
 the diffusion is rebuilt with ``timestep_respacing = str(sample_steps)`` and ``rescale_timesteps = True`` when
@@ -42,6 +54,12 @@ def main(argv=None):
     ap.add_argument("--synthetic-weights", type=int, default=None, help="seed: random-init weights (no checkpoint)")
     ap.add_argument("--x-T", default=None, help=".npy [N,1,H,W] start noise (default: torch.randn per batch, as the reference)")
     ap.add_argument("--gpus", type=int, default=1, help="ranks to start (one per GPU) when not already under torchrun")
+    ap.add_argument("--template-dir", default=None, help="<dir>/<id>/<template-name>: source volumes whose shape, dtype and header the predictions take")
+    ap.add_argument("--template-name", default=None, help="default: <last input key>.nii.gz")
+    ap.add_argument("--task-id", default=None, help="name the volumes <output>/<task-id>_<id>_pred.nii.gz (the trainer's naming)")
+    ap.add_argument("--gt-dir", default=None, help="<dir>/<id>/<gt-name>: ground truth volumes -> metric table <output>_metric.csv")
+    ap.add_argument("--gt-name", default="ce.nii.gz")
+    ap.add_argument("--mask-name", default=None, help="optional <gt-dir>/<id>/<mask-name> (> 0 = inside)")
     args = ap.parse_args(argv)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(_launch(args.gpus, sys.argv[1:] if argv is None else list(argv)))
@@ -71,7 +89,11 @@ def main(argv=None):
     uc = dict(mp["unet_config"])
     learn_sigma = bool(mp.get("learn_sigma", False))
     uc["params"] = dict(uc["params"], device_index=dev_index, out_channels=2 if learn_sigma else 1)  # trainer :69
-    unet = instantiate_from_config(uc)
+    if rank == 0:
+        unet = instantiate_from_config(uc)
+    else:
+        with parallel.empty_init():            # the values arrive by broadcast: no host initialisation on the other ranks
+            unet = instantiate_from_config(uc)
     if rank == 0:
         if args.ckpt:
             sd = torch.load(args.ckpt, map_location="cpu", weights_only=True)
@@ -87,7 +109,12 @@ def main(argv=None):
                         p.normal_(0.0, 0.02, generator=g)
         else:
             raise SystemExit("give --ckpt or --synthetic-weights")
-    parallel.broadcast_packed(dict(unet.named_parameters()), 0, dev)
+    if ws > 1:
+        # rank 0's weights in 256 MB buckets over RCCL, each uploaded into the library straight from the receive buffer
+        # (the analogue of Disc_diff/guided_diffusion/dist_util.py:54-83)
+        named = [(nm, tuple(p.shape)) for nm, p in unet.named_parameters()]
+        src = dict(unet.named_parameters()) if rank == 0 else None
+        parallel.broadcast_params_bucketed(named, (lambda nm: src[nm]) if rank == 0 else None, unet.upload_param, 0, dev)
 
     ss = icfg["sampler_setting"]
     steps_train = int(mp.get("diffusion_steps", 1000))
@@ -109,18 +136,26 @@ def main(argv=None):
         h5_paths = host_io.find_slice_files(args.input)
         if not h5_paths:
             raise SystemExit(f"no <id>/<name>_<slice>.h5 files under {args.input}")
-        cond_all = host_io.load_condition_slices(h5_paths, args.input_keys.split(","))
+        n = len(h5_paths)
+        mine = parallel.shard_indices(n, rank, ws)
+        keys = args.input_keys.split(",")
+        # every rank reads ITS slices only (memory O(N / R)); an empty shard still needs the slice shape
+        cond_mine = host_io.load_condition_slices([h5_paths[i] for i in mine], keys)
+        hw = cond_mine.shape[2:] if len(mine) else host_io.load_condition_slices(h5_paths[:1], keys).shape[2:]
+        fetch = lambda pos, idx: cond_mine[pos:pos + len(idx)]
     else:
         cond_all = np.load(args.input, mmap_mode="r")
+        n = cond_all.shape[0]
+        mine = parallel.shard_indices(n, rank, ws)
+        hw = cond_all.shape[2:]
+        fetch = lambda pos, idx: cond_all[idx]
     xT_all = np.load(args.x_T, mmap_mode="r") if args.x_T else None
-    n = cond_all.shape[0]
-    mine = parallel.shard_indices(n, rank, ws)
     bs = int(icfg.get("test_batch_size", 16))
     outs = []
     seeded = {} if which == "dpm" else {"seed": base_seed}   # DPM-Solver++ is deterministic after x_T
     for i in range(0, len(mine), bs):
         idx = mine[i:i + bs]
-        images = torch.from_numpy(np.ascontiguousarray(cond_all[idx])).float().to(dev)
+        images = torch.from_numpy(np.ascontiguousarray(fetch(i, idx))).float().to(dev)
         B, _, H, W = images.shape
         if xT_all is not None:
             noise = torch.from_numpy(np.ascontiguousarray(xT_all[idx])).float().to(dev)
@@ -130,17 +165,33 @@ def main(argv=None):
         outs.append(sample_fn(unet, (B, 1, H, W), noise=noise, clip_denoised=bool(mp.get("clip_denoised", True)),
                               model_kwargs=dict(c_concat=[images]), **extra, **seeded))
     unet.set_slice_ids(None)
-    local_out = torch.cat(outs) if outs else torch.zeros((0, 1) + tuple(cond_all.shape[2:]), device=dev)
+    local_out = torch.cat(outs) if outs else torch.zeros((0, 1) + tuple(hw), device=dev)
     full = parallel.gather_slices(local_out, n, 0)
     if rank == 0 and h5_paths is not None and not args.output.endswith(".npy"):
         from . import host_io
         asm = host_io.VolumeAssembler()
         asm.add_paths(h5_paths, full.cpu().numpy())
+        tname = args.template_name or (args.input_keys.split(",")[-1] + ".nii.gz")
+        written = {}
         for id_ in asm.ids():
-            os.makedirs(os.path.join(args.output, id_), exist_ok=True)
-            vol = asm.volume(id_)
-            host_io.write_nifti(os.path.join(args.output, id_, "pred.nii.gz"), vol)
-            print(f"wrote {os.path.join(args.output, id_, 'pred.nii.gz')}: {tuple(vol.shape)}")
+            template, thdr = (None, None)
+            if args.template_dir:
+                template, thdr = host_io.read_nifti(os.path.join(args.template_dir, id_, tname))
+            vol = asm.volume(id_, template=template)
+            if args.task_id is not None:
+                os.makedirs(args.output, exist_ok=True)
+                path = os.path.join(args.output, f"{args.task_id}_{id_}_pred.nii.gz")
+            else:
+                os.makedirs(os.path.join(args.output, id_), exist_ok=True)
+                path = os.path.join(args.output, id_, "pred.nii.gz")
+            host_io.write_nifti(path, vol, template_header=thdr)
+            written[id_] = path
+            print(f"wrote {path}: {tuple(vol.shape)} {vol.dtype}")
+        if args.gt_dir:
+            table = host_io.metric_table(written, args.gt_dir, args.gt_name, args.mask_name)
+            csv_path = args.output.rstrip("/") + "_metric.csv"
+            host_io.write_metric_csv(csv_path, table)
+            print(f"wrote {csv_path}: {len(table) - 1} ids + mean row")
     elif rank == 0:
         np.save(args.output, full.cpu().numpy())
         print(f"wrote {args.output}: {tuple(full.shape)}")

@@ -321,7 +321,9 @@ int dsd_bench_conv2d_stamps(int N, int H, int W, int Cin, int Cout, int warm, in
  * accumulator tile (one wave per SIMD, 160 accumulators, six products per group), `workgroups_per_cu` x 256 workgroups
  * (<= 0: 8), about `ms_target` milliseconds per launch, average of `iters` launches (hipEvents).  variant 0: operands in
  * registers (nothing but MFMAs: the upper bound at the clock the chip holds); 1: weight fragments re-read from LDS as the
- * convolution does; 2 / 3: the same two on all-zero operands.  *tflops = issued bf16 MFMA TFLOP/s.  (peak.hip) */
+ * convolution does; 2 / 3: the same two on all-zero operands; 4 .. 7: the same four with the work issued as
+ * v_mfma_f32_16x16x32_bf16 (the same output tile per wave, the same matrix-pipe cycles: the two shapes can hold different
+ * clocks under load).  *tflops = issued bf16 MFMA TFLOP/s.  (peak.hip) */
 int dsd_bench_mfma_peak(int variant, int workgroups_per_cu, float ms_target, int iters, float* avg_ms, double* tflops);
 /* How the library would run a convolution (host-side query, no GPU work): kernel structure (0 both operands staged
  * through LDS, 1 / 2 activations read straight into registers with a 128 / 256-row tile; -1 for the fp32 kernel), N-tile

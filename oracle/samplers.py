@@ -50,7 +50,7 @@ class DiffusionA:
             new_ts = new_ts.float() * (1000.0 / self.original_num_steps)
         return new_ts
 
-    def p_mean_variance(self, model, x, t, clip_denoised=True, cond=None):
+    def p_mean_variance(self, model, x, t, clip_denoised=True, cond=None, denoised_fn=None):
         T = self.tab
         B, C = x.shape[:2]
         x_in = x if cond is None else torch.cat([x] + list(cond), 1)     # DiffusionWrapper ddpm.py:1331-1333
@@ -65,7 +65,10 @@ class DiffusionA:
             log_var = _ext(np.log(np.append(T["posterior_variance"][1], self.betas[1:])), t, x.shape)
         else:
             log_var = _ext(T["posterior_log_variance_clipped"], t, x.shape)
-        clip = (lambda z: z.clamp(-1, 1)) if clip_denoised else (lambda z: z)
+        def clip(z):                                                       # process_xstart :311-316
+            if denoised_fn is not None:
+                z = denoised_fn(z)
+            return z.clamp(-1, 1) if clip_denoised else z
         if self.parameterization != "v":                                   # :318-333
             if self.predict_xstart:
                 x0 = clip(out)
@@ -80,22 +83,32 @@ class DiffusionA:
         return mean, log_var, x0
 
     @torch.no_grad()
-    def p_sample_loop(self, model, x_T, noise, cond=None, clip_denoised=True):
+    def p_sample_loop(self, model, x_T, noise, cond=None, clip_denoised=True, denoised_fn=None, cond_fn=None):
+        """cond_fn(x, t_model, c_concat=...) -> gradient; condition_mean :386-398 through SpacedDiffusion's timestep wrapping
+        (respace.py:94-100,123-128): mean += variance * gradient."""
         img = x_T
         for k, i in enumerate(reversed(range(self.num_timesteps))):
             t = torch.tensor([i] * x_T.shape[0])
-            mean, log_var, _ = self.p_mean_variance(model, img, t, clip_denoised, cond)
+            mean, log_var, _ = self.p_mean_variance(model, img, t, clip_denoised, cond, denoised_fn)
+            if cond_fn is not None:
+                grad = cond_fn(img, self.model_t(t), **({} if cond is None else dict(c_concat=list(cond))))
+                # p_mean_var["variance"] (:296-309): the variance TABLE, not exp(log_variance) — FIXED_SMALL pairs the raw
+                # posterior variance (0 at t = 0) with the clipped log
+                var = (np.append(self.tab["posterior_variance"][1], self.betas[1:]) if self.var_type == "fixed_large"
+                       else self.tab["posterior_variance"])
+                assert self.var_type != "learned_range"
+                mean = mean.float() + _ext(var, t, img.shape) * grad.float()
             nz = (t != 0).float().view(-1, 1, 1, 1)
             img = mean + nz * torch.exp(0.5 * log_var) * noise[k]          # :464
         return img
 
     @torch.no_grad()
-    def ddim_sample_loop(self, model, x_T, noise, cond=None, clip_denoised=True, eta=0.0):
+    def ddim_sample_loop(self, model, x_T, noise, cond=None, clip_denoised=True, eta=0.0, denoised_fn=None):
         T = self.tab
         img = x_T
         for k, i in enumerate(reversed(range(self.num_timesteps))):
             t = torch.tensor([i] * x_T.shape[0])
-            _, _, x0 = self.p_mean_variance(model, img, t, clip_denoised, cond)
+            _, _, x0 = self.p_mean_variance(model, img, t, clip_denoised, cond, denoised_fn)
             eps = (_ext(T["sqrt_recip_alphas_cumprod"], t, img.shape) * img - x0) \
                 / _ext(T["sqrt_recipm1_alphas_cumprod"], t, img.shape)     # :369-373
             ab = _ext(T["alphas_cumprod"], t, img.shape)

@@ -387,6 +387,51 @@ def gen_loops2():
 
 
 # ------------------------------------------------------------------ DPM-Solver(++) multistep (tiny model)
+def gen_hooks():
+    """The denoised_fn / cond_fn hooks of the family-A loops (gaussian_diffusion.py:312-313,386-398,460-463) on the tiny model:
+    denoised_fn = tanh(1.5 x) on the predicted x_start (before the clip), cond_fn = a gradient that pulls x towards the
+    condition image and grows with the (rescaled, float) model timestep it is handed — so the wrapped-timestep plumbing of
+    SpacedDiffusion.condition_mean (respace.py:94-100) is part of the fixture.  tests/test_sampling_gpu.py and
+    tests/test_oracle_golden.py spell the same two functions out."""
+    import Disc_diff.guided_diffusion.gaussian_diffusion as gd
+    from Disc_diff.guided_diffusion.respace import space_timesteps, SpacedDiffusion
+    out = {}
+    m, _ = tiny_model(TINY, 200)
+    shape = (2, 1, 32, 32)
+    cond = cond_image(shape, 80)
+    x_T = randn(shape, 81)
+    out["cond_seed"], out["xT_seed"] = np.asarray(80), np.asarray(81)
+    wrapped = lambda x, t, **kw: m(torch.cat([x] + kw["c_concat"], 1), t)[0]
+    denoised_fn = lambda x: torch.tanh(1.5 * x)
+    cond_fn = lambda x, t, **kw: -0.3 * (x - kw["c_concat"][0]) * (1.0 + t.float().view(-1, 1, 1, 1) / 1000.0)
+
+    def mk(respacing, param, var):
+        b = gd.get_named_beta_schedule("linear", 1000)
+        return SpacedDiffusion(use_timesteps=space_timesteps(1000, respacing), betas=b, model_mean_type=gd.ModelMeanType.EPSILON,
+                               model_var_type=var, loss_type=gd.LossType.MSE, rescale_timesteps=True, parameterization=param)
+
+    for key, diff, fn, nseed, kw in (
+            ("ddpm_20_v_denoised", mk("20", "v", gd.ModelVarType.FIXED_LARGE), "p_sample_loop", 301, dict(denoised_fn=denoised_fn)),
+            ("ddim_20_v_denoised_eta05", mk("20", "v", gd.ModelVarType.FIXED_LARGE), "ddim_sample_loop", 302,
+             dict(denoised_fn=denoised_fn, eta=0.5)),
+            ("ddpm_20_eps_small_denoised", mk("20", "eps", gd.ModelVarType.FIXED_SMALL), "p_sample_loop", 303, dict(denoised_fn=denoised_fn)),
+            ("ddpm_20_v_cond", mk("20", "v", gd.ModelVarType.FIXED_LARGE), "p_sample_loop", 304, dict(cond_fn=cond_fn)),
+            ("ddpm_25_eps_small_cond_denoised", mk("25", "eps", gd.ModelVarType.FIXED_SMALL), "p_sample_loop", 305,
+             dict(cond_fn=cond_fn, denoised_fn=denoised_fn))):
+        feed = _NoiseFeed(shape, nseed, diff.num_timesteps)
+        orig = torch.randn_like
+        torch.randn_like = feed
+        try:
+            y = getattr(diff, fn)(wrapped, shape, noise=x_T.clone(), clip_denoised=True, model_kwargs=dict(c_concat=[cond]),
+                                  device="cpu", **kw)
+        finally:
+            torch.randn_like = orig
+        assert feed.k == diff.num_timesteps
+        out[key + "_y"] = y.numpy()
+        out[key + "_noise_seed"] = np.asarray(nseed)
+    save("hooks", **out)
+
+
 def gen_dpm():
     """Disc_diff/guided_diffusion/sampler.py through its call site gaussian_diffusion.py:467-522, and the LDM twin
     ldm/models/diffusion/dpm_solver_new through DPMSolverSampler-style arguments (sampler.py:86-101)."""
@@ -572,6 +617,6 @@ def gen_temb():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "ops", "xattn", "model", "loops", "loops2", "dpm", "temb", "vae", "latent_unet"]
+    which = sys.argv[1:] or ["schedules", "ops", "xattn", "model", "loops", "loops2", "hooks", "dpm", "temb", "vae", "latent_unet"]
     for w in which:
         globals()["gen_" + w]()

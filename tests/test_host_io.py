@@ -101,3 +101,111 @@ def test_skimage_metrics_against_real_skimage():
     assert H.ssim(t, p, mask) == H.structural_similarity(tt, pp, win_size=9, data_range=tt.max() - tt.min())
     assert 0.5 < H.ssim(t, p, mask) < 1.0
     assert H.psnr(t, p, mask) == H.peak_signal_noise_ratio(t[sl], p[sl], data_range=t[sl].max() - t[sl].min())
+
+
+def _ms_ssim_torch(preds, target, betas=(0.0448, 0.2856, 0.3001, 0.2363, 0.1333)):
+    """Independent restatement of the published MS-SSIM in torch ops, laid out as a convolution pipeline (reflect padding,
+    2-D Gaussian kernel, crop) instead of host_io's separable scipy filters."""
+    import torch
+    import torch.nn.functional as F
+    x = torch.as_tensor(preds, dtype=torch.float64)[None, None]
+    y = torch.as_tensor(target, dtype=torch.float64)[None, None]
+    R = max(float(x.max() - x.min()), float(y.max() - y.min()))
+    c1, c2 = (0.01 * R) ** 2, (0.03 * R) ** 2
+    d = torch.arange(-5, 6, dtype=torch.float64)
+    g = torch.exp(-(d / 1.5) ** 2 / 2)
+    g = g / g.sum()
+    k = (g[:, None] * g[None, :])[None, None]
+    vals = []
+    for i in range(5):
+        xp, yp = F.pad(x, (5, 5, 5, 5), mode="reflect"), F.pad(y, (5, 5, 5, 5), mode="reflect")
+        stack = torch.cat([xp, yp, xp * xp, yp * yp, xp * yp])
+        mx, my, xx, yy, xy = F.conv2d(stack, k).split(1)
+        sx, sy, sxy = xx - mx * mx, yy - my * my, xy - mx * my
+        up, lo = 2 * sxy + c2, sx + sy + c2
+        full = ((2 * mx * my + c1) * up / ((mx * mx + my * my + c1) * lo))[..., 5:-5, 5:-5].mean()
+        cs = (up / lo)[..., 5:-5, 5:-5].mean()
+        vals.append(torch.relu(full if i == 4 else cs))
+        x, y = F.avg_pool2d(x, 2), F.avg_pool2d(y, 2)
+    return float(torch.prod(torch.stack(vals) ** torch.tensor(betas, dtype=torch.float64)))
+
+
+def test_ms_ssim_definition_and_reference_wrapper():
+    """MS-SSIM (what the reference's metric pass reports as "ssim", test_metrics.py:249-274 through torchmetrics): PARITY
+    UNPINNED (torchmetrics absent, no value of it in the reference) — checked against an independent torch restatement of
+    the published definition, its limiting cases, and the wrapper's crop / rescale / per-slice mean written out."""
+    rng = np.random.default_rng(5)
+    t = rng.uniform(0, 1, (200, 183))
+    assert abs(H.multiscale_structural_similarity(t, t) - 1.0) < 1e-12
+    prev = 1.0
+    for noise in (0.02, 0.1, 0.4):
+        p = t + noise * rng.standard_normal(t.shape)
+        v = H.multiscale_structural_similarity(p, t)
+        assert abs(v - _ms_ssim_torch(p, t)) < 1e-10 and 0.0 < v < prev
+        assert abs(v - H.multiscale_structural_similarity(t, p)) < 1e-12        # symmetric
+        prev = v
+    with pytest.raises(ValueError):
+        H.multiscale_structural_similarity(t[:150, :150], t[:150, :150])          # 5 scales of an 11-tap window need > 160 px
+    vol_t = rng.uniform(0, 1, (4, 190, 200))
+    vol_p = vol_t + 0.05 * rng.standard_normal(vol_t.shape)
+    mask = np.zeros(vol_t.shape, np.uint8)
+    mask[0:4, 5:190, 8:196] = 1
+    tt, pp = H.scale12bit((vol_t * mask)[0:3, 5:189, 8:195]), H.scale12bit((vol_p * mask)[0:3, 5:189, 8:195])
+    want = np.mean([H.multiscale_structural_similarity(pp[i], tt[i]) for i in range(3)])
+    keep = vol_t.copy()
+    assert abs(H.ssim_torch(vol_t, vol_p, mask) - want) < 1e-12 and np.array_equal(vol_t, keep)   # inputs are not modified
+
+
+def test_metric_table_and_csv(tmp_path):
+    """inference/get_metric_BraTs.py:54-126: one row per id (nrmse, smape, logac, medsymac, cc = 0, mi = NaN [ANTs, not built],
+    ssim = MS-SSIM, lpips = 0, fid = 0, psnr), the float32 mean row FIRST, header ids + the ten names."""
+    import csv
+    rng = np.random.default_rng(6)
+    gt_dir, pred_dir = tmp_path / "gt", tmp_path / "pred"
+    pred_dir.mkdir()
+    files = []
+    for k, id_ in enumerate(("0007", "0123", "0042")):
+        (gt_dir / id_).mkdir(parents=True)
+        gt = rng.uniform(0, 1, (3, 200, 208)).astype(np.float32)
+        H.write_nifti(str(gt_dir / id_ / "ce.nii.gz"), gt)
+        H.write_nifti(str(pred_dir / f"{id_}_task_pred.nii.gz"), (gt + 0.03 * (k + 1) * rng.standard_normal(gt.shape)).astype(np.float32))
+        files.append(str(pred_dir / f"{id_}_task_pred.nii.gz"))
+    (pred_dir / "notes.txt").write_text("x")
+    table = H.metric_table(files + [str(pred_dir / "notes.txt")], str(gt_dir))
+    assert [r[0] for r in table] == [0, "0007", "0123", "0042"] and all(len(r) == 11 for r in table)
+    rows = np.asarray([r[1:] for r in table[1:]], dtype=np.float32)
+    assert np.allclose(table[0][1:], rows.mean(axis=0), equal_nan=True)
+    col = {n: i + 1 for i, n in enumerate(H.METRIC_COLUMNS)}
+    gt0, _ = H.read_nifti(str(gt_dir / "0007" / "ce.nii.gz"))
+    p0, _ = H.read_nifti(files[0])
+    assert table[1][col["psnr"]] == H.psnr(gt0.astype(np.float64), p0.astype(np.float64))
+    assert table[1][col["ssim"]] == H.ssim_torch(gt0.astype(np.float64), p0.astype(np.float64)) and table[1][col["cc"]] == 0.0
+    assert np.isnan(table[1][col["mi"]]) and table[1][col["nrmse"]] < table[2][col["nrmse"]] < table[3][col["nrmse"]]
+    out = tmp_path / "m.csv"
+    H.write_metric_csv(str(out), table)
+    back = list(csv.reader(open(out)))
+    assert back[0] == ["ids"] + H.METRIC_COLUMNS and len(back) == 5 and back[2][0] == "0007"
+
+
+def test_host_io_robustness_cases(tmp_path):
+    """stray .h5 names are skipped with a warning, a NaN scl_slope means "no scaling", a 4-D header with a unit
+    time axis reads as a 3-D volume."""
+    d = tmp_path / "in" / "idA"
+    d.mkdir(parents=True)
+    for name in ("t1_0.h5", "t1_3.h5", "stats.h5", "export_final.h5"):
+        H.write_h5(str(d / name), {"F_Data1": np.zeros((4, 4), np.float32)})
+    with pytest.warns(UserWarning, match="skipped"):
+        found = H.find_slice_files(str(tmp_path / "in"))
+    assert [p.split("/")[-1] for p in found] == ["t1_0.h5", "t1_3.h5"]
+    vol = np.arange(24, dtype=np.int16).reshape(2, 3, 4)
+    p = str(tmp_path / "v.nii")
+    H.write_nifti(p, vol)
+    raw = bytearray(open(p, "rb").read())
+    struct.pack_into("<2f", raw, 112, float("nan"), 0.0)          # scl_slope = NaN
+    struct.pack_into("<8h", raw, 40, 4, 4, 3, 2, 1, 1, 1, 1)      # dim[0] = 4, trailing unit time axis
+    open(p, "wb").write(bytes(raw))
+    back, _ = H.read_nifti(p)
+    assert back.shape == (2, 3, 4) and back.dtype == np.int16 and np.array_equal(back, vol)
+    struct.pack_into("<2f", raw, 112, 2.0, 1.0)
+    open(p, "wb").write(bytes(raw))
+    assert np.array_equal(H.read_nifti(p)[0], vol.astype(np.float32) * 2 + 1)

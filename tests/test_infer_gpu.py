@@ -91,3 +91,54 @@ def test_infer_2d_h5_slices_to_nifti_volumes(tmp_path):
         assert vol.shape == (d, 32, 32)
         assert np.array_equal(vol, flat[k:k + d, 0])
         k += d
+
+
+def test_infer_2d_templates_task_naming_and_metric_csv(tmp_path):
+    """ADVICE r2 + f-2 remainder: with --template-dir the volumes take the template's depth (trailing unpredicted slices stay
+    zero), dtype and header bytes and --task-id names them <task>_<id>_pred.nii.gz (trainer_use_gaussian_diff.py:639-649);
+    --gt-dir runs the metric pass of inference/get_metric_BraTs.py over them and writes the table as CSV.  Sizes: 192x192
+    slices (the MS-SSIM of the "ssim" column needs > 160 px; also a width the yamls use that is not a power of two)."""
+    import csv
+    from diffusion_models_dsdiff_amd import host_io
+    gm = golden("model")
+    params = json.loads(str(gm["tiny_cfg"]))
+    sd = fixture_params(gm, "tiny")
+    model_yaml = {"model": {"params": {"parameterization": "v", "diffusion_steps": 1000, "noise_schedule": "linear",
+                                       "unet_config": {"target": "UNet_DS_Diff.model.DSUnetModel", "params": params}}}}
+    infer_yaml = {"cuda_idx": 0, "test_batch_size": 3, "seed": 11,
+                  "sampler_setting": {"sampler": "ddim", "sample_steps": 3, "ddim_eta": 0}}
+    (tmp_path / "m.yaml").write_text(yaml.safe_dump(model_yaml))
+    (tmp_path / "i.yaml").write_text(yaml.safe_dump(infer_yaml))
+    torch.save(sd, tmp_path / "ckpt.pt")
+    S = 192
+    cond = cond_image((4, 1, S, S), 77).numpy()
+    depth_template = {"p01": 4, "p02": 3}                       # predicted: p01 slices 0, 1 ; p02 slices 0, 2
+    pred_slices = {"p01": [0, 1], "p02": [0, 2]}
+    k = 0
+    for id_, zs in pred_slices.items():
+        os.makedirs(tmp_path / "h5" / id_)
+        os.makedirs(tmp_path / "tpl" / id_)
+        for z in zs:
+            host_io.write_h5(str(tmp_path / "h5" / id_ / f"t1_{z}.h5"), {"F_Data1": cond[k, 0]})
+            k += 1
+        host_io.write_h5(str(tmp_path / "h5" / id_ / "stats.h5"), {"F_Data1": np.zeros((2, 2), np.float32)})   # stray file: skipped
+        gt = np.random.default_rng(len(id_) + k).uniform(-1, 1, (depth_template[id_], S, S)).astype(np.float32)
+        host_io.write_nifti(str(tmp_path / "tpl" / id_ / "F_Data1.nii.gz"), gt, spacing=(3.0, 0.5, 0.5))
+        host_io.write_nifti(str(tmp_path / "tpl" / id_ / "ce.nii.gz"), gt, spacing=(3.0, 0.5, 0.5))
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "diffusion_models_dsdiff_amd.infer_2d", "--model-yaml", str(tmp_path / "m.yaml"),
+                        "--infer-yaml", str(tmp_path / "i.yaml"), "--ckpt", str(tmp_path / "ckpt.pt"), "--input", str(tmp_path / "h5"),
+                        "--input-keys", "F_Data1", "--output", str(tmp_path / "pred"), "--template-dir", str(tmp_path / "tpl"),
+                        "--task-id", "Task9", "--gt-dir", str(tmp_path / "tpl")],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    for id_, zs in pred_slices.items():
+        vol, hdr = host_io.read_nifti(str(tmp_path / "pred" / f"Task9_{id_}_pred.nii.gz"))
+        _, thdr = host_io.read_nifti(str(tmp_path / "tpl" / id_ / "F_Data1.nii.gz"))
+        assert vol.shape == (depth_template[id_], S, S) and vol.dtype == np.float32
+        assert hdr[76:108] == thdr[76:108] and hdr[252:344] == thdr[252:344]                 # the template's geometry
+        for z in range(depth_template[id_]):
+            assert bool(np.any(vol[z])) == (z in zs)                                         # unpredicted slices stay zero
+    rows = list(csv.reader(open(str(tmp_path / "pred") + "_metric.csv")))
+    assert rows[0] == ["ids"] + host_io.METRIC_COLUMNS and [r[0] for r in rows[1:]] == ["0", "p01", "p02"]
+    assert all(np.isfinite(float(v)) for r in rows[1:] for i, v in enumerate(r[1:]) if host_io.METRIC_COLUMNS[i] != "mi")

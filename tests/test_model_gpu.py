@@ -475,9 +475,24 @@ def test_data_edits_are_uploaded():
         p = dict(m.named_parameters())["out.2.weight"]
         p.data.view(-1)[1] += 0.5
         sd2["out.2.weight"] = p.detach().clone()
-    m.mark_dirty(["out.2.weight"])
+    # the documented contract — a PARTIAL .data edit (masked / sliced write) that misses the probed elements is
+    # not seen by itself (the forward still runs the old weights) ...
+    assert torch.equal(m(x.cuda(), t.cuda())[0], y1)
+    m.mark_dirty(["out.2.weight"])                                  # ... until it is announced
     y2, _ = m(x.cuda(), t.cuda())
-    assert rel_l2(y2, O.unet_forward(cfg, sd2, x, t)[0]) < TOL_MODEL
+    assert rel_l2(y2, O.unet_forward(cfg, sd2, x, t)[0]) < TOL_MODEL and not torch.equal(y2, y1)
+    # with the safety net switched off even a whole-tensor .data rewrite needs mark_dirty(); version-counted edits never do
+    m.detect_data_edits = False
+    with torch.no_grad():
+        p = dict(m.named_parameters())["out.2.bias"]
+        p.data.add_(0.25)
+        assert torch.equal(m(x.cuda(), t.cuda())[0], y2)
+        m.mark_dirty(["out.2.bias"])
+        y3 = m(x.cuda(), t.cuda())[0]
+        assert abs(float((y3 - y2).mean()) - 0.25) < 1e-5
+        p.add_(0.25)                                                # in-place op on the parameter: version counter
+        assert abs(float((m(x.cuda(), t.cuda())[0] - y3).mean()) - 0.25) < 1e-5
+    m.detect_data_edits = True
 
 
 def test_full_size_properties(full_model):

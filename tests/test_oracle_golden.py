@@ -263,6 +263,29 @@ def test_loops_more_branches():
 
 
 # ---------------------------------------------------------------------------------------- DPM-Solver(++) multistep
+# the two hook functions of tests/golden/hooks.npz (tests/golden/gen_golden.py::gen_hooks hands the same ones to the reference)
+HOOK_DENOISED = lambda x: torch.tanh(1.5 * x)
+HOOK_COND = lambda x, t, **kw: -0.3 * (x - kw["c_concat"][0]) * (1.0 + t.float().view(-1, 1, 1, 1) / 1000.0)
+HOOK_CASES = [("ddpm_20_v_denoised", dict(timestep_respacing="20", parameterization="v"), "ddpm", dict(denoised_fn=HOOK_DENOISED)),
+              ("ddim_20_v_denoised_eta05", dict(timestep_respacing="20", parameterization="v"), "ddim", dict(denoised_fn=HOOK_DENOISED, eta=0.5)),
+              ("ddpm_20_eps_small_denoised", dict(timestep_respacing="20", sigma_small=True), "ddpm", dict(denoised_fn=HOOK_DENOISED)),
+              ("ddpm_20_v_cond", dict(timestep_respacing="20", parameterization="v"), "ddpm", dict(cond_fn=HOOK_COND)),
+              ("ddpm_25_eps_small_cond_denoised", dict(timestep_respacing="25", sigma_small=True), "ddpm",
+               dict(cond_fn=HOOK_COND, denoised_fn=HOOK_DENOISED))]
+
+
+def test_loops_with_denoised_fn_and_cond_fn():
+    """gaussian_diffusion.py:312-313 (denoised_fn on the predicted x_start, before the clip), :386-398,460-463 (cond_fn:
+    mean += variance * gradient, timesteps wrapped by SpacedDiffusion) against loops the reference itself ran."""
+    gh = golden("hooks")
+    _, model, shape, cond, xT = _loop_setup()
+    for key, dkw, kind, kw in HOOK_CASES:
+        d = samplers.DiffusionA(steps=1000, rescale_timesteps=True, **dkw)
+        z = randn((d.num_timesteps,) + shape, int(gh[key + "_noise_seed"]))
+        fn = d.p_sample_loop if kind == "ddpm" else d.ddim_sample_loop
+        assert rel_l2(fn(model, xT, z, [cond], **kw), gh[key + "_y"]) < TOL_LOOP, key
+
+
 def test_dpm_schedule_tables():
     """NoiseScheduleVP('discrete') marginals and get_time_steps against the reference's fp32 values (bit-exact: same
     torch CPU primitives)."""

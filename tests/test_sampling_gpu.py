@@ -92,6 +92,36 @@ def test_learned_range_film_model_four_channels(env):
     assert rel_l2(y, gl["A_lr_ddim_20_y"]) < TOL
 
 
+def test_denoised_fn_and_cond_fn_hooks(env):
+    """gaussian_diffusion.py:312-313 (denoised_fn on the predicted x_start, before the clip), :386-398 / :460-463 (cond_fn shifts the
+    DDPM mean by variance * gradient; SpacedDiffusion hands it the wrapped model timestep) — against loops the REFERENCE ran
+    with the same two functions (tests/golden/hooks.npz).  The hooks run in Python between the network and the fused update
+    kernel; cond_fn + DDIM and cond_fn + learned variance raise and name the loop to use."""
+    from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
+    _, wrap, cond, xT, _ = env
+    gh = golden("hooks")
+    den = lambda x: torch.tanh(1.5 * x)
+    cfn = lambda x, t, **kw: -0.3 * (x - kw["c_concat"][0]) * (1.0 + t.float().view(-1, 1, 1, 1) / 1000.0)
+    cases = [("ddpm_20_v_denoised", dict(timestep_respacing="20", parameterization="v"), "p_sample_loop", dict(denoised_fn=den)),
+             ("ddim_20_v_denoised_eta05", dict(timestep_respacing="20", parameterization="v"), "ddim_sample_loop", dict(denoised_fn=den, eta=0.5)),
+             ("ddpm_20_eps_small_denoised", dict(timestep_respacing="20", sigma_small=True), "p_sample_loop", dict(denoised_fn=den)),
+             ("ddpm_20_v_cond", dict(timestep_respacing="20", parameterization="v"), "p_sample_loop", dict(cond_fn=cfn)),
+             ("ddpm_25_eps_small_cond_denoised", dict(timestep_respacing="25", sigma_small=True), "p_sample_loop",
+              dict(cond_fn=cfn, denoised_fn=den))]
+    for key, dkw, fn, kw in cases:
+        d = create_gaussian_diffusion(steps=1000, rescale_timesteps=True, **dkw)
+        z = randn((d.num_timesteps,) + SHAPE, int(gh[key + "_noise_seed"])).cuda()
+        for model in (wrap, wrap.diffusion_model):       # the DiffusionWrapper and the bare native U-Net
+            y = getattr(d, fn)(model, SHAPE, noise=xT, clip_denoised=True, model_kwargs=dict(c_concat=[cond]), step_noise=z, **kw)
+            assert rel_l2(y, gh[key + "_y"]) < TOL, key
+    d = create_gaussian_diffusion(steps=1000, timestep_respacing="20", rescale_timesteps=True, parameterization="v")
+    with pytest.raises(NotImplementedError, match="p_sample_loop"):
+        d.ddim_sample_loop(wrap, SHAPE, noise=xT, model_kwargs=dict(c_concat=[cond]), cond_fn=cfn)
+    d = create_gaussian_diffusion(steps=1000, timestep_respacing="20", rescale_timesteps=True, learn_sigma=True)
+    with pytest.raises(NotImplementedError, match="learn_sigma"):
+        d.p_sample_loop(wrap, SHAPE, noise=xT, model_kwargs=dict(c_concat=[cond]), cond_fn=cfn)
+
+
 def test_generic_callable_and_single_step_paths(env):
     """A foreign callable goes through the python loop + fused HIP update; p_sample returns pred_xstart."""
     from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion

@@ -72,7 +72,7 @@ def kernel_symbol(kind: str):
 
 def pmc_traffic(workload: str, kind: str):
     """HBM bytes per launch of `kind` from the committed PMC summary of this workload (tools/profile_workloads.sh), or None."""
-    path = os.path.join(ROOT, "profiles", f"r03_pmc_{workload}.json")
+    path = os.path.join(ROOT, "profiles", f"r03_pmc_{'latent' if workload.startswith('latent') else workload}.json")
     sym = kernel_symbol(kind)
     if not (os.path.exists(path) and sym):
         return None, None
