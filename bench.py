@@ -583,6 +583,20 @@ def run_rank(args):
                 if r["roofline"]:
                     modes["bf16x6+winograd"]["dominant_kernel"] = {k: r["roofline"][k] for k in (
                         "kernel", "achieved", "peak", "frac", "algorithmic_tflops", "avg_launch_ms", "mfma_products_per_fp32_product")}
+            # separate line: the tap-reuse kernel's matrix work issued as v_mfma_f32_16x16x32_bf16 (conv_tr16.hip),
+            # interleaved with the default shape in this process: A B A B, 3 steps each
+            if args.precision == "bf16x6":
+                ab = {0: [], 1: []}
+                for rnd in range(2):
+                    for on in (0, 1):
+                        _lib.lib().dsd_set_conv_mfma16(on)
+                        r = leg.measure(args.precision, 3, 1, 0, barrier, reduce_max)
+                        ab[on].append(r["ms_per_step"])
+                _lib.lib().dsd_set_conv_mfma16(0)
+                modes["bf16x6+mfma16x16x32"] = {"ms_per_step": round(min(ab[1]), 3), "value": round(B / (1000.0 * min(ab[1]) / 1e3), 6),
+                                               "ab_ms_per_step": {"32x32x16": ab[0], "16x16x32": ab[1]},
+                                               "note": "same-process interleaved A/B of the dominant kernel's MFMA shape; csrc/peak.hip bare loops: "
+                                                       "16x16x32 holds 1.13x (registers) / 1.06x (LDS-fed) the 32x32x16 rate on random data"}
             # separate line: the network evaluation of a step replayed as ONE captured hipGraph instead of ~800 host launches
             if not args.graph:
                 model.use_graph(True)

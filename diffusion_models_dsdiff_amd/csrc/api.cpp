@@ -520,6 +520,12 @@ int dsd_op_conv2d(const float* x, int N, int H, int W, int Cin, const float* w_o
     DSD_CATCH
 }
 
+int dsd_set_conv_mfma16(int on) {
+    const int prev = conv2d_get_mfma16();
+    conv2d_set_mfma16(on);
+    return prev;
+}
+
 int dsd_conv_plan(int N, int H, int W, int Cin, int Cout, int ks, int stride, int precision, int* structure, int* nt,
                   int* ksplit, uint64_t* scratch_bytes) {
     DSD_TRY

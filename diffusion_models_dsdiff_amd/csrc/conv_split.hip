@@ -115,6 +115,15 @@ static bool tr_enabled() {
     static const int mode = getenv("DSD_CONV_TR") ? atoi(getenv("DSD_CONV_TR")) : 1;   // DSD_CONV_TR=0: the plain A-direct kernel (A/B)
     return mode > 0;
 }
+// the tap-reuse kernel with its matrix work issued as v_mfma_f32_16x16x32_bf16 (conv_tr16.hip): DSD_CONV_MFMA16=1 / 0
+void launch_split_tr16(const SplitP& p, dim3 grid, hipStream_t s);
+static int g_mfma16 = -1;
+static bool mfma16_enabled() {
+    if (g_mfma16 < 0) g_mfma16 = getenv("DSD_CONV_MFMA16") ? atoi(getenv("DSD_CONV_MFMA16")) : 0;
+    return g_mfma16 > 0;
+}
+void conv2d_set_mfma16(int on) { g_mfma16 = on ? 1 : 0; }
+int conv2d_get_mfma16() { return mfma16_enabled() ? 1 : 0; }
 static bool tr_shape_ok(int ks, int stride, int pad, int OW, int IWg, int OH, int IHg, int ksplit, int out_nchw, int ohw, int64_t M, int Cin) {
     return ks == 3 && stride == 1 && pad == 1 && OW == IWg && OH == IHg && ksplit == 1 && !out_nchw &&
            (OW == 32 || OW == 64 || OW == 128 || OW == 256) && ohw % (2 * SBM) == 0 && M % (2 * SBM) == 0 && Cin % SBK == 0;
@@ -138,6 +147,11 @@ static void launch_split(const SplitP& p, int nt, hipStream_t s, int ad) {   // 
         if (!(ad == 2 && nt == 5 && NP == 3 && !F16 && p.ksplit == 1)) fail("conv stamps: only the dominant kernel (256-row tile, 160 columns, bf16x6) has the diagnostic build");
         launch_split_diag(p, grid, s);
         check_launch("conv_split_ad2_stamped");
+        return;
+    }
+    if (ad == 2 && nt == 5 && NP == 3 && !F16 && conv_tr_ok(p) && mfma16_enabled()) {   // the same kernel on v_mfma_f32_16x16x32_bf16 (conv_tr16.hip)
+        launch_split_tr16(p, grid, s);
+        check_launch("conv_split_tr16");
         return;
     }
     if (ad == 2 && nt == 5 && NP == 3 && !F16 && conv_tr_ok(p)) {

@@ -62,6 +62,9 @@ void conv2d(ConvArgs a, hipStream_t s);
 void split_weights(const float* w, int64_t n, int np, void* planes, hipStream_t s, bool f16 = false, int* ovf = nullptr);
 bool conv2d_split_eligible(const ConvArgs& a);
 bool conv2d_split_tr(const ConvArgs& a, int nt, int ksplit, int ad);   // the tap-reuse instantiation would take it
+// process-wide switch of the tap-reuse kernel's MFMA shape (0: 32x32x16, 1: 16x16x32 — conv_tr16.hip); A/B runs in one process
+void conv2d_set_mfma16(int on);
+int conv2d_get_mfma16();
 bool conv2d_fuses_gn(const ConvArgs& a);   // conv2d(a) can apply GroupNorm + SiLU to its input itself (a.gn_scale / a.gn_shift)
 void conv2d_split(const ConvArgs& a, int nt, int ksplit, int structure, hipStream_t s);
 double conv2d_flops(const ConvArgs& a);

@@ -328,6 +328,11 @@ int dsd_bench_mfma_peak(int variant, int workgroups_per_cu, float ms_target, int
 /* How the library would run a convolution (host-side query, no GPU work): kernel structure (0 both operands staged
  * through LDS, 1 / 2 activations read straight into registers with a 128 / 256-row tile; -1 for the fp32 kernel), N-tile
  * width in 32-column units, split-K factor and the scratch bytes the split needs.  precision as in dsd_op_conv2d_prec. */
+/* Process-wide switch (experiment): the dominant convolution kernel (256 x 160 tile, bf16x6, tap reuse,
+ * optional fused GroupNorm) with its matrix work issued as v_mfma_f32_16x16x32_bf16 (conv_tr16.hip) instead of
+ * v_mfma_f32_32x32x16_bf16.  Same results up to fp32 summation order.  Default: the environment variable
+ * DSD_CONV_MFMA16 (0).  Returns the previous setting. */
+int dsd_set_conv_mfma16(int on);
 int dsd_conv_plan(int N, int H, int W, int Cin, int Cout, int ks, int stride, int precision, int* structure, int* nt,
                   int* ksplit, uint64_t* scratch_bytes);
 /* GroupNorm(32, C, eps) [+ SiLU] on x[N,HW,C]. */

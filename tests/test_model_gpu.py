@@ -633,3 +633,26 @@ def test_gn_apply_inside_the_consuming_convolution(full_model):
     xs, ts = randn((1, 2, 64, 64), 5), torch.tensor([731])
     yo = O.unet_forward(cfg, sd, xs, ts)[0]
     assert rel_l2(m._run(xs.cuda(), ts.cuda(), want_feats=False)[0], yo) < 1e-5
+
+
+def test_mfma16_shape_full_size(full_model):
+    """dsd_set_conv_mfma16: the 88 + 3 tap-reuse launches of a step (with the fused GroupNorm apply and the epilogue
+    statistics) on the 16x16x32 MFMA shape — the full network at 256x256 against the oracle (<= 1e-5, as the default kernel)
+    and against the default kernel (fp32 summation order only)."""
+    from diffusion_models_dsdiff_amd import _lib
+    L = _lib.lib()
+    m, cfg, sd = full_model
+    m.set_precision("bf16x6")
+    x = randn((2, 2, 256, 256), 195)
+    t = torch.tensor([321, 7])
+    yo = O.unet_forward(cfg, sd, x[1:], t[1:])[0]
+    y32 = m._run(x.cuda(), t.cuda(), want_feats=False)[0]
+    prev = L.dsd_set_conv_mfma16(1)
+    try:
+        y16 = m._run(x.cuda(), t.cuda(), want_feats=False)[0]
+        assert torch.equal(y16, m._run(x.cuda(), t.cuda(), want_feats=False)[0])     # deterministic
+    finally:
+        L.dsd_set_conv_mfma16(prev)
+    e16, e32 = rel_l2(y16[1:], yo), rel_l2(y32[1:], yo)
+    print(f"full-size forward 256x256 bf16x6: 16x16x32 shape rel-L2 {e16:.3e}, 32x32x16 {e32:.3e}, between them {rel_l2(y16, y32):.3e}")
+    assert e16 < 1e-5 and e32 < 1e-5 and rel_l2(y16, y32) < 5e-6 and not torch.equal(y16, y32)

@@ -371,3 +371,37 @@ def test_conv2d_row_tiles(ops, case):
     yy, rr = ops.to_nchw(y).double().cpu(), ref
     for sl in ((..., 0, slice(None)), (..., H - 1, slice(None)), (..., slice(None), 0), (..., slice(None), W - 1)):
         assert rel_l2(yy[sl], rr[sl]) < PREC_TOL["bf16x6"], (case, sl)
+
+
+@pytest.mark.parametrize("case", TR_CASES)
+def test_conv2d_row_tiles_mfma16(ops, case):
+    """The tap-reuse kernel with its matrix work issued as v_mfma_f32_16x16x32_bf16 (conv_tr16.hip, dsd_set_conv_mfma16): the
+    same cases, the same float64 bar, every epilogue fusion on; and the two MFMA shapes agree to fp32 summation order."""
+    from diffusion_models_dsdiff_amd import _lib
+    L = _lib.lib()
+    N, H, W, Cin, Cout = case[:5]
+    ups = len(case) > 5 and case[5]
+    g = torch.Generator().manual_seed(sum(case[:5]) + 5)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    emb = torch.randn(N, Cout, generator=g)
+    xin = F.interpolate(x, scale_factor=2, mode="nearest") if ups else x
+    H, W = xin.shape[2:]
+    res = torch.randn(N, Cout, H, W, generator=g)
+    ref = F.conv2d(xin.double(), w.double(), b.double(), padding=1) + emb.double()[:, :, None, None] + res.double()
+    args = (cu(ops.to_nhwc(x)), cu(w), cu(b))
+    kw = dict(upsample=bool(ups), emb=cu(emb), res=cu(ops.to_nhwc(res)), precision="bf16x6")
+    prev = L.dsd_set_conv_mfma16(1)
+    try:
+        y16 = ops.conv2d(*args, **kw)
+    finally:
+        L.dsd_set_conv_mfma16(prev)
+    y32 = ops.conv2d(*args, **kw)
+    assert rel_l2(ops.to_nchw(y16), ref) < PREC_TOL["bf16x6"], case
+    assert rel_l2(y16, y32) < 1e-6
+    if case[:5] == (1, 256, 256, 32, 320):
+        assert not torch.equal(y16, y32)          # a different kernel really ran (the planner gives this shape the 256 x 160 tile)
+    yy = ops.to_nchw(y16).double().cpu()
+    for sl in ((..., 0, slice(None)), (..., H - 1, slice(None)), (..., slice(None), 0), (..., slice(None), W - 1)):
+        assert rel_l2(yy[sl], ref[sl]) < PREC_TOL["bf16x6"], (case, sl)

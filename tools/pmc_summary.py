@@ -19,6 +19,27 @@ meta = {"precision": sys.argv[5] if len(sys.argv) > 5 else "bf16x6", "git_head":
         "method": "rocprofv3 --kernel-trace --pmc, one pass per counter group; FETCH_SIZE x2 (gfx950), KiB -> bytes"}
 
 
+def demangle(name):
+    """rocprofv3 leaves kernels whose template arguments are _Float16 / __bf16 mangled (and the image has no llvm-cxxfilt):
+    spell the few such symbols of this library out — _ZN3dsd3g1613gemm16_kernelIDF16_Li2EEEvNS0_4G16PE ->
+    dsd::g16::gemm16_kernel<_Float16, 2>."""
+    import re
+    if not name.startswith("_ZN"):
+        return name
+    i, parts = 3, []
+    while i < len(name) and name[i].isdigit():
+        j = i
+        while name[j].isdigit():
+            j += 1
+        n = int(name[i:j])
+        parts.append(name[j:j + n])
+        i = j + n
+    m = re.match(r"I(DF16_|DF16b)(?:Li(\d+)E)?E", name[i:])
+    if not parts or not m:
+        return name
+    return "::".join(parts) + f"<{'_Float16' if m.group(1) == 'DF16_' else '__bf16'}{', ' + m.group(2) if m.group(2) is not None else ''}>"
+
+
 def load(path):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
     with open(path) as f:
@@ -40,7 +61,7 @@ du = durations(sq_dir + "/p_kernel_trace.csv")
 res = {}
 for k in sorted(fe, key=lambda k: -sum(du.get(k, [0]))):
     n = len(fe[k]["FETCH_SIZE"])
-    if n == 0 or "dsd::" not in k:
+    if n == 0 or ("dsd::" not in k and not k.startswith("_ZN3dsd")):
         continue
     rd = 2.0 * sum(fe[k]["FETCH_SIZE"]) * 1024.0
     wb = sum(wr[k]["WRITE_SIZE"]) * 1024.0
@@ -61,7 +82,7 @@ for k in sorted(fe, key=lambda k: -sum(du.get(k, [0]))):
                                 "active": round(s.get("SQ_ACTIVE_INST_ANY", 0) / s["SQ_WAVE_CYCLES"], 3)}
     if s.get("SQ_LDS_IDX_ACTIVE"):
         e["lds_bank_conflict_frac"] = round(s.get("SQ_LDS_BANK_CONFLICT", 0) / s["SQ_LDS_IDX_ACTIVE"], 4)
-    res[k.replace("void ", "")[:110]] = e   # (long enough for every template argument of the convolution kernels)
+    res[demangle(k).replace("void ", "")[:110]] = e   # (long enough for every template argument of the convolution kernels)
 res["_meta"] = meta
 json.dump(res, open(out + ".json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
