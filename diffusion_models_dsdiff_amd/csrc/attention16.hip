@@ -72,8 +72,22 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(A16P a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, half = lane >> 5;
-    const int n = blockIdx.z, head = blockIdx.y;
-    const int q = blockIdx.x * 128 + wave * 32 + lrow;
+    // block -> (query block, head, sample).  The 32 query blocks of one (sample, head) re-read the same K / V (1 MB at 4096
+    // tokens of 64): with the hardware's round-robin of consecutive blocks over the 8 XCDs every XCD's L2 would fetch every
+    // head (PMC, round 3: 4.5x the algorithmic bytes from beyond L2); here workgroups b and b + 8 — the same XCD — walk the
+    // query blocks of the same head, so a head's K / V is fetched by ONE L2.  Placement only: any mapping is correct.
+    const int QB = (a.Tq + 127) / 128, HB = a.heads * a.N;
+    int bid = blockIdx.x, hb, qb;
+    if ((HB & 7) == 0) {
+        const int slot = bid >> 3;
+        hb = (slot / QB) * 8 + (bid & 7);
+        qb = slot - (slot / QB) * QB;
+    } else {
+        hb = bid / QB;
+        qb = bid - hb * QB;
+    }
+    const int n = hb / a.heads, head = hb - n * a.heads;
+    const int q = qb * 128 + wave * 32 + lrow;
     const bool q_ok = q < a.Tq;
     const int hch = a.d >> 3;   // valid 16-byte chunks per row
 
@@ -150,10 +164,12 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(A16P a) {
         for (int sub = 0; sub < KEYS / 32; ++sub) {
             if (k0 + sub * 32 >= a.Tk) break;
             // S^T[key][q] - m = sum_d K[key][d] Q[q][d] + (-m)
-            f32x16 sacc = F::mfma(*reinterpret_cast<const typename F::v8*>(Kl + sub * 1024 + kofs), qf[0], negm);
+            typename F::v8 kf[NKS];   // all fragment reads first: their latencies overlap instead of queueing in front of each MFMA
 #pragma unroll
-            for (int s = 1; s < NKS; ++s)
-                sacc = F::mfma(*reinterpret_cast<const typename F::v8*>(Kl + s * KPL + sub * 1024 + kofs), qf[s], sacc);
+            for (int s = 0; s < NKS; ++s) kf[s] = *reinterpret_cast<const typename F::v8*>(Kl + s * KPL + sub * 1024 + kofs);
+            f32x16 sacc = F::mfma(kf[0], qf[0], negm);
+#pragma unroll
+            for (int s = 1; s < NKS; ++s) sacc = F::mfma(kf[s], qf[s], sacc);
             if (k0 + sub * 32 + 32 > a.Tk) {   // last, partial sub-tile: keys beyond Tk take no part
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -230,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(A16P a) {
 
 template <typename T16>
 void launch_attn16(const A16P& p, int nks, hipStream_t s) {
-    const dim3 grid(cdiv(p.Tq, 128), p.heads, p.N), block(256);
+    const dim3 grid((unsigned)(cdiv(p.Tq, 128) * p.heads * p.N)), block(256);
     switch (nks) {
         case 1: hipLaunchKernelGGL((attention16_kernel<T16, 1>), grid, block, 0, s, p); break;
         case 2: hipLaunchKernelGGL((attention16_kernel<T16, 2>), grid, block, 0, s, p); break;

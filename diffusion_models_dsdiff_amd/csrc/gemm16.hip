@@ -13,8 +13,10 @@
 // is lane-linear in LDS, so the bank swizzle sits on the SOURCE address (cdna_hip_programming.md rule 21): tile rows are
 // 128 B (64 k), 16-byte chunk c of row r is stored at chunk c ^ ((r >> 1) & 7), and the fragment reads (ds_read_b128, lane =
 // row, 8 consecutive k) apply the same XOR — conflict-free for the 16x16x32 operand pattern (checked lane group by lane
-// group against MI355X_MICROARCH.md §LDS).  Rows beyond M / N and chunks beyond K are fetched from a 16-byte zero buffer.
-// Loop: stage tile t+1, multiply tile t, one barrier (+ vmcnt(0)) per k-tile.
+// group against MI355X_MICROARCH.md §LDS).  The DMA uses buffer addressing: rows beyond M / N and chunks beyond K get an
+// out-of-range offset (zeros), and the k-tile advances through the scalar offset — no vector address work in the loop.
+// Loop: stage tile t+1, multiply tile t, one barrier (+ vmcnt(0)) per k-tile; the fragments of the tile's second k-step are
+// read while the first one multiplies.
 //
 // Fused epilogues (what DiTBlock.forward does around each Linear):
 //   EPI_STORE   y16 = round16(acc + bias)             columns < qcols first multiplied by qscale (the attention's q scale)
@@ -33,8 +35,6 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
 constexpr int GBM = 256, GBN = 256, GBK = 64;
 constexpr int G_TILE_BYTES = GBN * GBK * 2;   // 32 KB per operand and stage
@@ -59,6 +59,12 @@ struct Frag<__bf16> {
 __device__ __forceinline__ float gelu_tanh_f(float v) {
     const float u2 = -2.f * 0.7978845608028654f * 1.4426950408889634f * (v + 0.044715f * v * v * v);   // -2u log2(e)
     return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(u2));
+}
+
+// 16 B per lane from a buffer resource straight into LDS (lane-linear from the wave-uniform `lds`).  A __device__ function of
+// its own: the target builtin directly inside a __global__ template makes the HOST pass drop the instantiation silently.
+static __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds, unsigned voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (void __attribute__((address_space(3)))*)lds, 16, voff, soff, 0, 0);
 }
 
 struct G16P {
@@ -94,31 +100,37 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
     const int bm0 = tile_m * GBM, bn0 = tile_n * GBN;
 
     // ---- staging: per k-tile 4 + 4 LDS-DMA pieces per thread.  Piece j of wave w covers tile rows 64 j + 8 w .. + 8; lane ->
-    // row + (lane >> 3), physical chunk lane & 7, logical chunk (lane & 7) ^ ((row >> 1) & 7)
+    // row + (lane >> 3), physical chunk lane & 7, logical chunk (lane & 7) ^ ((row >> 1) & 7).  Buffer addressing: the
+    // per-lane byte offset of a piece is fixed for the whole k-loop (rows beyond M / N get an out-of-range offset: the
+    // hardware delivers zeros), the k-tile advances through the SCALAR offset — no vector address arithmetic in the loop.
     const int srow = wave * 8 + (lane >> 3);                       // + 64 j
     const int schunk = (lane & 7) ^ ((srow >> 1) & 7);             // ((64 j + srow) >> 1) & 7 == (srow >> 1) & 7
-    const T16* zero = reinterpret_cast<const T16*>(g_zero16);
-    const T16* wsrc[4];
-    const T16* xsrc[4];
+    const int rows_w = min(p.N - bn0, GBN), rows_x = min(p.M - bm0, GBM);
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const T16*>(p.w) + (int64_t)bn0 * p.K), 0, (unsigned)rows_w * (unsigned)p.K * 2u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(reinterpret_cast<const T16*>(p.x) + (int64_t)bm0 * p.ldx), 0,
+        ((unsigned)(rows_x - 1) * (unsigned)p.ldx + (unsigned)p.K) * 2u, 0x00020000);
+    unsigned wvo[4], xvo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int n = bn0 + j * 64 + srow, m = bm0 + j * 64 + srow;
-        wsrc[j] = n < p.N ? reinterpret_cast<const T16*>(p.w) + (int64_t)n * p.K + schunk * 8 : nullptr;
-        xsrc[j] = m < p.M ? reinterpret_cast<const T16*>(p.x) + (int64_t)m * p.ldx + schunk * 8 : nullptr;
+        const int r = j * 64 + srow;
+        wvo[j] = r < rows_w ? ((unsigned)r * (unsigned)p.K + (unsigned)schunk * 8u) * 2u : 0xFFFFFFF0u;
+        xvo[j] = r < rows_x ? ((unsigned)r * (unsigned)p.ldx + (unsigned)schunk * 8u) * 2u : 0xFFFFFFF0u;
     }
-    auto stage = [&](int buf, int k0) {
-        const bool kok = k0 + schunk * 8 < p.K;
+    // one DMA piece (q = 0..3: W rows 64 q .., q = 4..7: X rows) of the k-tile at k0 into stage `buf`
+    auto stage_piece = [&](int buf, int k0, int q, bool tail) {
         unsigned char* base = lds + buf * (2 * G_TILE_BYTES) + wave * 1024;
+        const int so = __builtin_amdgcn_readfirstlane(k0 * 2);
+        // last, partial k-tile: chunks beyond K are zeros (a row's tail would otherwise read its neighbour's head)
+        const bool kok = !tail || k0 + schunk * 8 < p.K;
+        if (q < 4) dma16(rw, base + q * 8192, kok ? wvo[q] : 0xFFFFFFF0u, so);
+        else dma16(rxb, base + G_TILE_BYTES + (q - 4) * 8192, kok ? xvo[q - 4] : 0xFFFFFFF0u, so);
+    };
+    auto stage = [&](int buf, int k0) {
+        const bool tail = k0 + GBK > p.K;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const T16* s = (wsrc[j] && kok) ? wsrc[j] + k0 : zero;
-            __builtin_amdgcn_global_load_lds((const void*)s, (__attribute__((address_space(3))) void*)(base + j * 8192), 16, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const T16* s = (xsrc[j] && kok) ? xsrc[j] + k0 : zero;
-            __builtin_amdgcn_global_load_lds((const void*)s, (__attribute__((address_space(3))) void*)(base + G_TILE_BYTES + j * 8192), 16, 0, 0);
-        }
+        for (int q = 0; q < 8; ++q) stage_piece(buf, k0, q, tail);
     };
 
     // ---- fragment read offsets: lane -> row (lane & 15) of a 16-row tile, k chunk 4 ks + (lane >> 4), XOR ((row >> 1) & 7)
@@ -136,22 +148,30 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
     const int nkt = (p.K + GBK - 1) / GBK;
     stage(0, 0);
     __syncthreads();   // (emits vmcnt(0): the first tile has landed)
+    typename F::v8 af[2][8], bf[2][4];
+    auto read_frags = [&](const unsigned char* sb, int ks, typename F::v8 (&a)[8], typename F::v8 (&b)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const typename F::v8*>(sb + ((boff + j * 2048) ^ (ks * 64)));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = *reinterpret_cast<const typename F::v8*>(sb + ((aoff + i * 2048) ^ (ks * 64)));
+    };
+    // (Measured and dropped, round 3: the 8 DMA pieces of the next k-tile spread over the MFMA stream, one per group of 4 MFMAs,
+    // waves 0-3 during the first k-step and waves 4-7 during the second — 740 instead of 825 TF/s: with vmcnt(0) in front of
+    // the tile's barrier a late piece is a late tile.  A spread issue needs the counted-vmcnt, three-stage structure of
+    // cdna_hip_programming.md's 8-phase template, which half-tile LDS stages would have to make room for.)
     for (int t = 0; t < nkt; ++t) {
         const int buf = t & 1;
-        if (t + 1 < nkt) stage(buf ^ 1, (t + 1) * GBK);
         const unsigned char* sb = lds + buf * (2 * G_TILE_BYTES);
+        read_frags(sb, 0, af[0], bf[0]);
+        if (t + 1 < nkt) stage(buf ^ 1, (t + 1) * GBK);
+        read_frags(sb, 1, af[1], bf[1]);          // the second k-step's fragments are on their way while the first one multiplies
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            typename F::v8 af[8], bf[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const typename F::v8*>(sb + ((boff + j * 2048) ^ (ks * 64)));
-#pragma unroll
-            for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const typename F::v8*>(sb + ((aoff + i * 2048) ^ (ks * 64)));
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = F::mfma(af[i], bf[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = F::mfma(af[ks][i], bf[ks][j], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
         }
         __syncthreads();   // vmcnt(0) + barrier: tile t+1 has landed, every wave is done reading tile t
