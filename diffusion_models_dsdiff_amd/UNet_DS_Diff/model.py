@@ -116,6 +116,12 @@ class NativeModule(nn.Module):
         check(lib().dsd_set_fuse_gn_apply(self._h, int(on)))
         return self
 
+    def stream_lanes(self, on: bool = True, max_pixels: int = 0):
+        """Run the four encoder streams concurrently on four HIP streams where their layers are too small to fill the chip
+        (default) or one after the other (include/dsdiff.h: dsd_set_stream_lanes); bit-identical either way."""
+        check(lib().dsd_set_stream_lanes(self._h, int(on), int(max_pixels)))
+        return self
+
     def graph_stats(self):
         c, l = C.c_int(), C.c_int()
         check(lib().dsd_graph_stats(self._h, C.byref(c), C.byref(l)))

@@ -258,6 +258,19 @@ int dsd_set_fuse_gn_apply(dsd_handle* h, int on) {
     DSD_CATCH
 }
 
+int dsd_set_stream_lanes(dsd_handle* h, int on, int max_pixels) {
+    DSD_TRY
+    DSD_CHECK(h, "null handle");
+    const int px = max_pixels > 0 ? max_pixels : h->lane_pixels;
+    if (h->use_lanes != (on != 0) || h->lane_pixels != px) {
+        h->use_lanes = on != 0;
+        h->lane_pixels = px;
+        h->plan.valid = false;   // the emission order of the plan (and what the arena may recycle) depends on it
+        net_drop_graph(h);
+    }
+    DSD_CATCH
+}
+
 int dsd_set_winograd(dsd_handle* h, int on) {
     DSD_TRY
     DSD_CHECK(h, "null handle");

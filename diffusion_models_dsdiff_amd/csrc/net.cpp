@@ -620,6 +620,11 @@ void dsd::net_free(dsd_handle* h) {
     h->param_evs.clear();
     if (h->gexec) (void)hipGraphExecDestroy(h->gexec);
     if (h->cap_stream) (void)hipStreamDestroy(h->cap_stream);
+    if (h->lane_fork) (void)hipEventDestroy(h->lane_fork);
+    for (int l = 0; l < 3; ++l) {
+        if (h->lane_join[l]) (void)hipEventDestroy(h->lane_join[l]);
+        if (h->lane_stream[l]) (void)hipStreamDestroy(h->lane_stream[l]);
+    }
     for (auto& kv : h->wsplit) (void)hipFree(kv.second);
     h->wsplit.clear();
     h->wsplit_bytes.clear();
@@ -645,6 +650,22 @@ struct Builder {
     hipStream_t ps;          // plan-time device work (weight pieces) goes on the caller's stream
     bool split_any = false;
     Builder(dsd_handle* h, Plan& p, int b, hipStream_t s) : hd(h), plan(p), B(b), ps(s) {}
+    // ---- stream lanes: between begin_parallel() and end_parallel() ops carry the current lane and NOTHING is recycled (lanes run
+    // concurrently: a buffer freed by one must not be handed to another while the first may still be reading it)
+    int lane = -1;
+    bool parallel = false;
+    std::vector<std::pair<size_t, size_t>> deferred;
+    void begin_parallel() { parallel = true; }
+    void set_lane(int l) { lane = l; }
+    void end_parallel() {
+        parallel = false;
+        lane = -1;
+        for (auto& d : deferred) ar.release(d.first, d.second);
+        deferred.clear();
+    }
+    void free_bytes(size_t off, size_t bytes) {
+        if (parallel) deferred.emplace_back(off, bytes); else ar.release(off, bytes);
+    }
 
     Tn alloc(int n, int h, int w, int c, int esz = 4) {
         Tn t;
@@ -713,18 +734,19 @@ struct Builder {
         return y;
     }
     void release(Tn& t) {
-        if (t.valid()) ar.release(t.off, t.bytes());
+        if (t.valid()) free_bytes(t.off, t.bytes());
         t.off = (size_t)-1;
         for (auto& st : t.st) {   // the statistics that travelled with the tensor die with it
-            if (st.valid()) ar.release(st.off, st.bytes(t.n));
+            if (st.valid()) free_bytes(st.off, st.bytes(t.n));
             st = StatRef{};
         }
     }
     size_t alloc_raw(size_t bytes) { return ar.alloc(bytes); }
-    void release_raw(size_t off, size_t bytes) { ar.release(off, bytes); }
+    void release_raw(size_t off, size_t bytes) { free_bytes(off, bytes); }
     void op(std::function<void(hipStream_t)> f, int launches = 1, const std::string& kind = "misc", double flops = 0.0,
             double bytes = 0.0) {
         plan.ops.push_back(std::move(f));
+        plan.op_lane.push_back((signed char)(parallel ? lane : -1));
         plan.launches += launches;
         int k = -1;
         for (size_t i = 0; i < plan.kind_names.size(); ++i)
@@ -1408,19 +1430,42 @@ void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats, bool 
 
     // ---- four encoder streams (model.py:674-686): stream order n, a, al, l ; planes io.plane[0..3]
     const char* sfx[4] = {"", "_a", "_al", "_l"};
+    // Emission order: first the blocks whose layers fill the chip, stream after stream; then — from the first block whose
+    // input has few enough pixels (dsd_handle::lane_pixels) — the rest of the four encoders as four LANES that the executor
+    // runs concurrently (net_launch_ops): small grids of independent chains share the 256 CUs instead of queueing.
     std::vector<Tn> hs[4];
-    for (int s = 0; s < 4; ++s) {
+    Tn cur4[4];
+    size_t split = sp.input_blocks.size();
+    {
+        int hh = H, ww = W;
+        for (size_t bi = 0; bi < sp.input_blocks.size() && split == sp.input_blocks.size(); ++bi) {
+            if (hd->use_lanes && (int64_t)B * hh * ww <= hd->lane_pixels && bi > 0) split = bi;
+            for (const Layer& L : sp.input_blocks[bi])
+                if (L.kind == L_DOWN || (L.kind == L_RES && L.down)) { hh /= 2; ww /= 2; }
+        }
+    }
+    auto run_blocks = [&](int s, size_t from, size_t to) {
         const std::string base = std::string("input_blocks") + sfx[s];
         auto embs = embs_for(base, sp.input_blocks);
-        Tn cur;
-        cur.n = (share && s >= 2) ? 1 : B; cur.h = H; cur.w = W; cur.c = 1;  // the caller's plane
-        for (size_t bi = 0; bi < sp.input_blocks.size(); ++bi) {
+        for (size_t bi = from; bi < to; ++bi) {
             size_t ei = 0;
-            Tn nxt = b.block(base + "." + std::to_string(bi), sp.input_blocks[bi], cur, /*keep_input=*/true, embs[bi], ei,
+            Tn nxt = b.block(base + "." + std::to_string(bi), sp.input_blocks[bi], cur4[s], /*keep_input=*/true, embs[bi], ei,
                              bi == 0 ? s : -1);
             hs[s].push_back(nxt);
-            cur = nxt;
+            cur4[s] = nxt;
         }
+    };
+    for (int s = 0; s < 4; ++s) {
+        cur4[s].n = (share && s >= 2) ? 1 : B; cur4[s].h = H; cur4[s].w = W; cur4[s].c = 1;  // the caller's plane
+        run_blocks(s, 0, split);
+    }
+    if (split < sp.input_blocks.size()) {
+        b.begin_parallel();
+        for (int s = 0; s < 4; ++s) {
+            b.set_lane(s);
+            run_blocks(s, split, sp.input_blocks.size());
+        }
+        b.end_parallel();
     }
     // ---- middle block on the noise stream only (model.py:688)
     Tn h_n;
@@ -2063,11 +2108,63 @@ void dsd::net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int
     p.valid = true;
 }
 
+void dsd::net_launch_ops(dsd_handle* h, hipStream_t s) {
+    Plan& p = h->plan;
+    bool any_lane = false;
+    if (h->use_lanes)
+        for (signed char l : p.op_lane) any_lane |= l > 0;
+    if (!any_lane) {
+        for (auto& f : p.ops) f(s);
+        return;
+    }
+    if (!h->lane_fork) {
+        DSD_HIP(hipEventCreateWithFlags(&h->lane_fork, hipEventDisableTiming));
+        for (int l = 0; l < 3; ++l) {
+            DSD_HIP(hipStreamCreateWithFlags(&h->lane_stream[l], hipStreamNonBlocking));
+            DSD_HIP(hipEventCreateWithFlags(&h->lane_join[l], hipEventDisableTiming));
+        }
+    }
+    unsigned active = 0;      // bit l: lane l (1..3) has work in flight since the last join
+    bool forked = false;      // the fork event of the current region has been recorded
+    auto join = [&]() {
+        for (int l = 1; l <= 3; ++l)
+            if (active & (1u << l)) {
+                DSD_HIP(hipEventRecord(h->lane_join[l - 1], h->lane_stream[l - 1]));
+                DSD_HIP(hipStreamWaitEvent(s, h->lane_join[l - 1], 0));
+            }
+        active = 0;
+        forked = false;
+    };
+    for (size_t i = 0; i < p.ops.size(); ++i) {
+        const int L = p.op_lane[i];
+        if (L < 0) {                       // sequential op: everything the lanes produced is its potential input
+            if (active) join();
+            forked = false;
+            p.ops[i](s);
+            continue;
+        }
+        if (!forked) {                     // first op of a region: lanes may start once everything before it is done
+            DSD_HIP(hipEventRecord(h->lane_fork, s));
+            forked = true;
+        }
+        if (L == 0) {                      // lane 0 is the caller's stream itself
+            p.ops[i](s);
+            continue;
+        }
+        if (!(active & (1u << L))) {
+            DSD_HIP(hipStreamWaitEvent(h->lane_stream[L - 1], h->lane_fork, 0));
+            active |= 1u << L;
+        }
+        p.ops[i](h->lane_stream[L - 1]);
+    }
+    if (active) join();
+}
+
 void dsd::net_run(dsd_handle* h, hipStream_t s) {
     DSD_CHECK(h->plan.valid, "no plan");
     Plan& p = h->plan;
     if (!h->profiling) {
-        for (auto& f : p.ops) f(s);
+        net_launch_ops(h, s);
         ++p.eager_runs;
         return;
     }
@@ -2156,7 +2253,7 @@ void dsd::net_run_cached(dsd_handle* h, hipStream_t s) {
     hipGraph_t graph = nullptr;
     DSD_HIP(hipStreamBeginCapture(h->cap_stream, hipStreamCaptureModeThreadLocal));
     try {
-        for (auto& f : h->plan.ops) f(h->cap_stream);
+        net_launch_ops(h, h->cap_stream);   // (lane streams join the capture through the fork event and leave it at the join)
     } catch (...) {
         (void)hipStreamEndCapture(h->cap_stream, &graph);
         if (graph) (void)hipGraphDestroy(graph);

@@ -76,6 +76,7 @@ struct Plan {
     int aux_len = 0, aux_len2 = 0;
     bool valid = false;
     std::vector<std::function<void(hipStream_t)>> ops;
+    std::vector<signed char> op_lane;   // -1: the caller's stream after joining every lane; 0..3: encoder stream lanes (run concurrently)
     std::vector<int> op_kind;        // index into kind_names
     std::vector<double> op_flops;    // algorithmic FLOPs of the op (0 for memory-bound ops)
     std::vector<double> op_bytes;    // algorithmic bytes (read+write) of the op (0 if not tracked)
@@ -146,6 +147,14 @@ struct dsd_handle {
     int use_winograd = 0;    // bf16x6 only, opt-in: 3x3 stride-1 convolutions as F(2,3) along the width (conv_wino.hip)
     int fuse_gn_stats = 1;   // GroupNorm statistics from the producing kernel's epilogue (0: always the standalone pass)
     int fuse_gn_apply = 1;   // GroupNorm + SiLU applied by the consuming 3x3 convolution while it stages its input (0: apply pass)
+    // The four encoder streams are independent chains (UNet_DS_Diff/model.py:674-686).  Where their layers are too small to fill
+    // 256 CUs (pixels per layer <= lane_pixels), the plan tags them with a lane and the executor runs lanes 1..3 on streams of
+    // its own between a fork and a join event: four under-filled grids share the chip instead of queueing.  Same kernels,
+    // same arithmetic: bit-identical to the sequential order.  dsd_set_stream_lanes.
+    int use_lanes = 1;
+    int lane_pixels = 16384;
+    hipStream_t lane_stream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t lane_fork = nullptr, lane_join[3] = {nullptr, nullptr, nullptr};
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;
     dsd::GraphKey gkey;
@@ -180,6 +189,8 @@ void net_set_param(dsd_handle* h, const char* name, const float* src, const int6
 void net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int want_feats, int aux_len, int aux_len2,
               int share = 0, hipStream_t s = nullptr);
 void net_run(dsd_handle* h, hipStream_t s);
+// every op of the plan in order; lane-tagged ops on the lane streams (fork / join through events) unless lanes are off
+void net_launch_ops(dsd_handle* h, hipStream_t s);
 // the same forward through the captured hipGraph when one is valid for the current plan and bindings (sampling loops)
 void net_run_cached(dsd_handle* h, hipStream_t s);
 void net_drop_graph(dsd_handle* h);

@@ -119,6 +119,14 @@ int dsd_set_fuse_gn_stats(dsd_handle* h, int on);
  * hardware exp2 / reciprocal (~1 ulp each) instead of expf and an IEEE division: the outputs agree with the apply-pass route
  * to fp32 rounding (measured 1e-7 relative on the network output), not bit for bit.  0 = always the separate pass. */
 int dsd_set_fuse_gn_apply(dsd_handle* h, int on);
+/* The four encoder streams of DSUnetModel (noise, a, al, l: UNet_DS_Diff/model.py:674-686) are independent chains until the
+ * skip average.  ON by default: from the first encoder block whose input has at most `max_pixels` pixels (batch x H x W;
+ * <= 0 keeps the current value, default 16384) the four streams are launched on four HIP streams (the caller's + three of
+ * the library's, forked and joined through events inside dsd_forward / dsd_sample, also under hipGraph capture), so that
+ * four grids too small to fill 256 CUs share the chip instead of queueing.  Same kernels, same operands: results are
+ * bit-identical to on = 0 (every stream in turn on the caller's stream).  The caller sees one stream: work submitted to it
+ * after the call is ordered after the join. */
+int dsd_set_stream_lanes(dsd_handle* h, int on, int max_pixels);
 /* bf16x6 mode only, OFF by default: 3x3 stride-1 convolutions whose grid fills the chip at least twice (>= 512 workgroups),
  * with an output width that is a power of two <= 256, Cin % 32 == 0 and Cout = 0 or 64 (mod 128), run as Winograd F(2,3)
  * ALONG THE WIDTH — 4 instead of 6 products per pair of outputs and filter row, i.e. 1.5x fewer MFMAs.  The input transform

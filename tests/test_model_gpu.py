@@ -656,3 +656,38 @@ def test_mfma16_shape_full_size(full_model):
     e16, e32 = rel_l2(y16[1:], yo), rel_l2(y32[1:], yo)
     print(f"full-size forward 256x256 bf16x6: 16x16x32 shape rel-L2 {e16:.3e}, 32x32x16 {e32:.3e}, between them {rel_l2(y16, y32):.3e}")
     assert e16 < 1e-5 and e32 < 1e-5 and rel_l2(y16, y32) < 5e-6 and not torch.equal(y16, y32)
+
+
+def test_stream_lanes_are_bit_identical(full_model):
+    """dsd_set_stream_lanes: the small encoder levels of the four streams on four HIP streams (fork / join events) against the
+    sequential order — the same kernels on the same operands, so bit for bit the same, eagerly and under hipGraph replay, at
+    batch 1 (lanes from 128x128 down), batch 3 and with the lane threshold forced to cover every level below the first; five
+    forwards in a row each (a missing dependency shows up as a changing or different result)."""
+    from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
+    from diffusion_models_dsdiff_amd._sched import run_device_loop
+    m, _, _ = full_model
+    m.set_precision("bf16x6")
+    for B, px in ((1, 0), (3, 0), (2, 1 << 22)):
+        x = randn((B, 4, 256, 256), 600 + B)
+        t = (torch.arange(B) * 331 + 5) % 1000
+        m.stream_lanes(False)
+        want = m._run(x.cuda(), t.cuda(), want_feats=False)[0]
+        n_seq = m.plan_info()["launches"]
+        m.stream_lanes(True, px if px else 16384)
+        for _ in range(5):
+            got = m._run(x.cuda(), t.cuda(), want_feats=False)[0]
+            assert torch.equal(got, want), (B, px)
+        assert m.plan_info()["launches"] == n_seq
+    # inside the sampling loop, eager and replayed from the captured graph
+    d = create_gaussian_diffusion(steps=1000, parameterization="v")
+    sched = d._schedule(False, 0.0, True)
+    shape = (1, 1, 256, 256)
+    cond, xT = cond_image_(shape, 611).cuda(), randn(shape, 612).cuda()
+    outs = []
+    for lanes, graph in ((False, False), (True, False), (True, True)):
+        m.stream_lanes(lanes)
+        m.use_graph(graph)
+        outs.append(run_device_loop(m, sched, xT, cond, seed=3, first_step=0, n_steps=4))
+    m.use_graph(False)
+    m.stream_lanes(True)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])

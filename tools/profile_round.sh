@@ -3,7 +3,7 @@
 #   GIT_HEAD=<sha> tools/profile_round.sh r02 [precision]  -> profiles/<tag>_kernel_stats.{txt,json}, profiles/<tag>_pmc[_prec].json
 # (copied to gpurun_out/profiles/ so they come back from the GPU box; GIT_HEAD is recorded as provenance)
 # Counters are collected in their own runs (--kernel-trace + --pmc only), as the pool requires.
-set -e
+set +e
 TAG=${1:-r01}
 PREC=${2:-bf16x6}
 R=$(cd "$(dirname "$0")/.." && pwd)
