@@ -8,7 +8,7 @@ TAG=${1:-r01}
 PREC=${2:-bf16x6}
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-profile --no-modes --precision $PREC"
+B="python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-profile --no-modes --no-workloads --repeats 1 --precision $PREC"
 O=$R/gpurun_out
 SUF=""; [ "$PREC" != "bf16x6" ] && SUF="_$PREC"
 rm -rf $O/prof_$TAG$SUF $O/pmc_fetch $O/pmc_write $O/pmc_sq
