@@ -774,6 +774,40 @@ int dsd_op_gemm_half(const float* x, const float* w, const float* bias, int M, i
     DSD_CATCH
 }
 
+int dsd_bench_gemm_half(int M, int N, int K, int bf16, int epi, int whatif, int iters, float* avg_ms) {
+    DSD_TRY
+    DSD_CHECK(iters >= 1 && avg_ms && M > 0 && N > 0 && K > 0, "bad argument");
+    hipStream_t s = nullptr;
+    Tmp xf((size_t)M * K * 4), wf((size_t)N * K * 4), x16((size_t)M * K * 2), w16((size_t)N * K * 2), y16((size_t)M * N * 2), b((size_t)N * 4);
+    Tmp x32(epi == EPI16_GATED ? (size_t)M * N * 4 : 256), gate(epi == EPI16_GATED ? (size_t)N * 4 : 256);
+    philox_normal(xf.as<float>(), (int64_t)M * K, 1, 0, s);
+    philox_normal(wf.as<float>(), (int64_t)N * K, 2, 0, s);
+    philox_normal(b.as<float>(), N, 3, 0, s);
+    cast16(xf.as<float>(), (int64_t)M * K, x16.p, bf16, s);
+    cast16(wf.as<float>(), (int64_t)N * K, w16.p, bf16, s);
+    if (epi == EPI16_GATED) {
+        DSD_HIP(hipMemsetAsync(x32.p, 0, (size_t)M * N * 4, s));
+        philox_normal(gate.as<float>(), N, 4, 0, s);
+    }
+    Gemm16Args a;
+    a.x = x16.p; a.ldx = K; a.w = w16.p; a.bias = b.as<float>(); a.M = M; a.N = N; a.K = K; a.bf16 = bf16; a.epi = epi;
+    a.y16 = y16.p; a.ldy = N; a.x32 = x32.as<float>(); a.ldx32 = N; a.gate = gate.as<float>(); a.gate_stride = 0; a.T = M;
+    gemm16_whatif(a, whatif, s);
+    hipEvent_t e0, e1;
+    DSD_HIP(hipEventCreate(&e0));
+    DSD_HIP(hipEventCreate(&e1));
+    DSD_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) gemm16_whatif(a, whatif, s);
+    DSD_HIP(hipEventRecord(e1, s));
+    DSD_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    DSD_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    DSD_CATCH
+}
+
 int dsd_op_attention_half(const float* qkv, int N, int T, int C, int heads, int bf16, float thr, float* out, void* stream) {
     DSD_TRY
     DSD_CHECK(qkv && out && heads > 0 && C % heads == 0, "C=%d not divisible by heads=%d", C, heads);

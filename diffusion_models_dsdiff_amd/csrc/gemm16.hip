@@ -79,7 +79,9 @@ struct G16P {
     int tiles_m, tiles_n;
 };
 
-template <typename T16, int EPI>
+// WI: what-if bits of the diagnostic instantiations (dsd_bench_gemm_half; results are then garbage): 1 no LDS-DMA staging in the
+// loop, 2 fragments read from LDS once (not per k-tile), 4 no epilogue, 8 no barrier
+template <typename T16, int EPI, int WI = 0>
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
     using F = Frag<T16>;
     __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * G_TILE_BYTES];   // [stage][W tile | X tile]
@@ -162,9 +164,9 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
     for (int t = 0; t < nkt; ++t) {
         const int buf = t & 1;
         const unsigned char* sb = lds + buf * (2 * G_TILE_BYTES);
-        read_frags(sb, 0, af[0], bf[0]);
-        if (t + 1 < nkt) stage(buf ^ 1, (t + 1) * GBK);
-        read_frags(sb, 1, af[1], bf[1]);          // the second k-step's fragments are on their way while the first one multiplies
+        if (!(WI & 2) || t == 0) read_frags(sb, 0, af[0], bf[0]);
+        if (t + 1 < nkt && !(WI & 1)) stage(buf ^ 1, (t + 1) * GBK);
+        if (!(WI & 2) || t == 0) read_frags(sb, 1, af[1], bf[1]);   // the second k-step's fragments are on their way while the first one multiplies
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             __builtin_amdgcn_s_setprio(1);
@@ -174,7 +176,16 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
                 for (int j = 0; j < 4; ++j) acc[i][j] = F::mfma(af[ks][i], bf[ks][j], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
         }
-        __syncthreads();   // vmcnt(0) + barrier: tile t+1 has landed, every wave is done reading tile t
+        if (!(WI & 8)) __syncthreads();   // vmcnt(0) + barrier: tile t+1 has landed, every wave is done reading tile t
+    }
+    if (WI & 4) {   // (diagnostic) keep the accumulators alive without the stores
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123.456f) reinterpret_cast<float*>(p.y16)[0] = t;
+        return;
     }
 
     // ---- epilogue.  acc[i][j][r]: n = bn0 + wn*128 + 16 i + 4 (lane >> 4) + r, m = bm0 + wm*64 + 16 j + (lane & 15).
@@ -304,13 +315,28 @@ template <typename T16, int EPI>
 void launch_gemm16(const G16P& p, hipStream_t s) {
     hipLaunchKernelGGL((gemm16_kernel<T16, EPI>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, s, p);
 }
+void launch_gemm16_whatif(const G16P& p, int wi, hipStream_t s) {
+    const dim3 g((unsigned)(p.tiles_m * p.tiles_n)), b(512);
+    switch (wi) {
+        case 0: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 0>), g, b, 0, s, p); break;
+        case 1: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 1>), g, b, 0, s, p); break;
+        case 2: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 2>), g, b, 0, s, p); break;
+        case 3: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 3>), g, b, 0, s, p); break;
+        case 4: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 4>), g, b, 0, s, p); break;
+        case 7: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 7>), g, b, 0, s, p); break;
+        case 15: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 15>), g, b, 0, s, p); break;
+        default: fail("gemm16 what-if %d is not instantiated (0, 1, 2, 3, 4, 7, 15)", wi);
+    }
+}
 
 }  // namespace g16
 using namespace g16;
 
 bool gemm16_shape_ok(int M, int N, int K) { return M >= 1 && N >= 4 && K >= 8 && N % 4 == 0 && K % 8 == 0; }
 
-void gemm16(const Gemm16Args& a, hipStream_t s) {
+void gemm16(const Gemm16Args& a, hipStream_t s) { gemm16_whatif(a, -1, s); }
+
+void gemm16_whatif(const Gemm16Args& a, int whatif, hipStream_t s) {
     DSD_CHECK(gemm16_shape_ok(a.M, a.N, a.K), "gemm16: M=%d N=%d K=%d unsupported (N %% 4, K %% 8)", a.M, a.N, a.K);
     DSD_CHECK(a.ldx % 8 == 0 && a.ldx >= a.K, "gemm16: ldx=%d must be a multiple of 8 and >= K", a.ldx);
     G16P p{};
@@ -324,6 +350,11 @@ void gemm16(const Gemm16Args& a, hipStream_t s) {
         DSD_CHECK(a.x32 && a.gate && a.ldx32 % 4 == 0 && a.gate_stride % 4 == 0, "gemm16: gated epilogue needs x32 / gate (strides %% 4)");
     } else {
         DSD_CHECK(a.y16 && a.ldy % 4 == 0, "gemm16: 16-bit output missing or ldy %% 4 != 0");
+    }
+    if (whatif >= 0) {
+        launch_gemm16_whatif(p, whatif, s);
+        check_launch("gemm16_whatif");
+        return;
     }
     if (a.bf16) {
         switch (a.epi) {

@@ -151,6 +151,7 @@ struct Gemm16Args {
 };
 bool gemm16_shape_ok(int M, int N, int K);
 void gemm16(const Gemm16Args& a, hipStream_t s);
+void gemm16_whatif(const Gemm16Args& a, int whatif, hipStream_t s);   // diagnostic instantiations (timing only), -1 = the product kernel
 void cast16(const float* x, int64_t n, void* y, int bf16, hipStream_t s);      // fp32 -> fp16 / bf16, round to nearest even
 void uncast16(const void* x, int64_t n, float* y, int bf16, hipStream_t s);
 // ln_modulate (misc.hip) with a 16-bit result: the A operand of the following Linear

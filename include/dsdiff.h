@@ -356,6 +356,11 @@ int dsd_op_qkv_attention(const float* qkv, int N, int T, int C, int heads, int n
  * 2: y (fp32, in/out) += gate[(m / T), :] * round16(acc + bias) — the adaLN-Zero gated residual (:120-121). */
 int dsd_op_gemm_half(const float* x, const float* w, const float* bias, int M, int N, int K, int bf16, int epi,
                      const float* gate, int T, float* y, void* stream);
+/* Timing of the half-precision GEMM kernel on random operands (hipEvents, average of `iters` launches after one warm-up).
+ * whatif < 0: the product kernel with epilogue `epi`; whatif >= 0: a diagnostic instantiation with costs removed (bits: 1 no
+ * LDS-DMA staging in the loop, 2 fragments read from LDS only once, 4 no epilogue, 8 no barrier; instantiated: 0, 1, 2, 3, 4,
+ * 7, 15) whose results are garbage — tools/gemm_whatif.py. */
+int dsd_bench_gemm_half(int M, int N, int K, int bf16, int epi, int whatif, int iters, float* avg_ms);
 /* softmax(q k^T * d^-1/2) v of timm Attention on qkv[N,T,3C] (q | k | v, heads inside each) -> a[N,T,C], 16-bit operands,
  * fp32 softmax statistics; thr: running-maximum threshold in log2 units (< 0: the library's default). */
 int dsd_op_attention_half(const float* qkv, int N, int T, int C, int heads, int bf16, float thr, float* a, void* stream);
