@@ -808,6 +808,39 @@ int dsd_bench_gemm_half(int M, int N, int K, int bf16, int epi, int whatif, int 
     DSD_CATCH
 }
 
+int dsd_bench_attention_half(int N, int T, int C, int heads, int bf16, int whatif, int iters, float* avg_ms) {
+    DSD_TRY
+    DSD_CHECK(iters >= 1 && avg_ms && heads > 0 && C % heads == 0, "bad argument");
+    hipStream_t s = nullptr;
+    const int d = C / heads;
+    Tmp qf((size_t)N * T * 3 * C * 4), q16((size_t)N * T * 3 * C * 2), o16((size_t)N * T * C * 2);
+    philox_normal(qf.as<float>(), (int64_t)N * T * 3 * C, 5, 0, s);
+    cast16(qf.as<float>(), (int64_t)N * T * 3 * C, q16.p, bf16, s);
+    Attn16Args a;
+    a.N = N; a.Tq = a.Tk = T; a.heads = heads; a.d = d;
+    a.ldq = a.ldk = a.ldv = 3 * C; a.ldo = C;
+    a.q_hs = a.k_hs = a.v_hs = d;
+    a.q = q16.p;
+    a.k = (const char*)q16.p + (size_t)C * 2;
+    a.v = (const char*)q16.p + (size_t)2 * C * 2;
+    a.bf16 = bf16;
+    a.out = o16.p;
+    attention16_whatif(a, whatif, s);
+    hipEvent_t e0, e1;
+    DSD_HIP(hipEventCreate(&e0));
+    DSD_HIP(hipEventCreate(&e1));
+    DSD_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) attention16_whatif(a, whatif, s);
+    DSD_HIP(hipEventRecord(e1, s));
+    DSD_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    DSD_HIP(hipEventElapsedTime(&ms, e0, e1));
+    *avg_ms = ms / iters;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    DSD_CATCH
+}
+
 int dsd_op_attention_half(const float* qkv, int N, int T, int C, int heads, int bf16, float thr, float* out, void* stream) {
     DSD_TRY
     DSD_CHECK(qkv && out && heads > 0 && C % heads == 0, "C=%d not divisible by heads=%d", C, heads);

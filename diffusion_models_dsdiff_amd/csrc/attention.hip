@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256, NKS <= 4 ? 2 : 1) void attention_split_kernel(
     constexpr int KEYS = 64;                 // keys per LDS stage = two 32-key sub-tiles
     constexpr int DT = (NKS + 1) / 2;        // 32-wide d tiles of O^T
     constexpr int CH = 2 * NKS;              // 8-float chunk slots per key row
-    constexpr int KPL = KEYS * 32 + 32;      // bytes per (piece, k-step) plane of K (+32: the planes of a key row land on different banks)
+    constexpr int KPL = KEYS * 32 + (NKS == 2 ? 64 : NKS == 3 ? 96 : 32);      // bytes per (piece, k-step) plane of K (+32: the planes of a key row land on different banks)
     constexpr int VPL = KEYS * 64 + 64;      // bytes per (piece, d-tile) plane of V
     constexpr int KPC = NKS * KPL, VPC = DT * VPL;   // one piece
     constexpr int NLD = (KEYS * CH + 255) / 256;

@@ -2,7 +2,7 @@
 // the attention of the transformer backbone in the arithmetic BASELINE configs[4] names (timm Attention under fp16 autocast,
 // UNet_DS_Diff/DiT_models.py:101-122: q k^T and attn v are half-precision matmuls, the softmax is fp32).
 //
-// One workgroup = (sample, head, 128 queries), 4 waves x 32 queries, 64 keys per LDS stage.
+// One workgroup = (sample, head, 128 queries), 4 waves x 32 queries, 64 keys per LDS stage, two stages (one barrier per tile).
 //   * S^T = K Q^T (v_mfma_f32_32x32x16): the lane owns ONE query column, so the row maximum / sum are in-lane plus one
 //     exchange with the other lane half, and exp2(S^T) is already the B operand of O^T = V^T P^T: P never leaves registers.
 //     The accumulator gives a lane the keys 4h + (r & 3) + 8 (r >> 2) of a 32-key sub-tile; k-step s of the second product
@@ -57,18 +57,20 @@ struct A16P {
     float thr;       // rescale threshold in log2 units
 };
 
-template <typename T16, int NKS>
+// WI: what-if bits of the diagnostic instantiations (dsd_bench_attention_half; results are then garbage): 1 no softmax arithmetic
+// (P = the raw scores), 2 no K / V staging after the first tile (no global loads, LDS writes or barriers in the loop), 4 no
+// second product (no V reads, no P V MFMAs), 8 no first product (no K reads, no Q K^T MFMAs)
+template <typename T16, int NKS, int WI = 0>
 __global__ __launch_bounds__(256, 2) void attention16_kernel(A16P a) {
     using F = AF<T16>;
     constexpr int KEYS = 64;
     constexpr int DT = (NKS + 1) / 2;        // 32-wide d tiles of O^T
     constexpr int CH = 2 * NKS;              // 16-byte chunk slots per key row (K side)
-    constexpr int KPL = KEYS * 32 + 32;      // bytes per K plane (+32: the planes of one key row land on different banks)
+    constexpr int KPL = KEYS * 32 + (NKS == 2 ? 64 : NKS == 3 ? 96 : 32);      // bytes per K plane; the pad spreads the planes that 8 consecutive staging lanes write (1-2 key rows) over all 32 banks
     constexpr int VPL = KEYS * 64 + 64;      // bytes per V plane
     constexpr int NLD = (KEYS * CH + 255) / 256;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NKS * KPL + DT * VPL];
-    unsigned char* Kl = lds;
-    unsigned char* Vl = lds + NKS * KPL;
+    constexpr int STG = NKS * KPL + DT * VPL;   // one stage (K planes | V planes); two stages: ONE barrier per 64-key tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, half = lane >> 5;
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(A16P a) {
     const int hch = a.d >> 3;   // valid 16-byte chunks per row
 
     // zero the whole stage once: padding chunks (d >= head dim) are never written again
-    for (int i = tid * 16; i < NKS * KPL + DT * VPL; i += 256 * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0u, 0u, 0u, 0u};
+    for (int i = tid * 16; i < 2 * STG; i += 256 * 16) *reinterpret_cast<u32x4*>(lds + i) = u32x4{0u, 0u, 0u, 0u};
 
     // Q^T fragments (B operand of S^T = K Q^T): this lane's query, k-step s covers d = 16 s + 8 half .. + 8
     typename F::v8 qf[NKS];
@@ -145,31 +147,48 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(A16P a) {
     const int g = lane >> 4, li = lane & 15;
     const int vofs = (4 * half + (li >> 2)) * 64 + (16 * (g & 1) + 4 * (li & 3)) * 2;         // + t * VPL + sub * 2048 + s2 * 1024 + j * 512
 
-    fetch(0);
-    bool first = true;
-    for (int k0 = 0; k0 < a.Tk; k0 += KEYS) {
-        __syncthreads();   // every wave is done with the previous tile (and, the first time, the zero fill has landed)
+    auto stage_write = [&](int st) {
+        unsigned char* Kw = lds + st * STG;
+        unsigned char* Vw = Kw + NKS * KPL;
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int i = tid + j * 256;
             const int kr = i / CH, c = i - kr * CH;
             if (kr < KEYS && c < hch) {
-                *reinterpret_cast<u32x4*>(Kl + (c >> 1) * KPL + ((kr * 32 + (c & 1) * 16) ^ (((kr >> 3) & 1) << 4))) = kreg[j];
-                *reinterpret_cast<u32x4*>(Vl + (c >> 2) * VPL + kr * 64 + (c & 3) * 16) = vreg[j];
+                *reinterpret_cast<u32x4*>(Kw + (c >> 1) * KPL + ((kr * 32 + (c & 1) * 16) ^ (((kr >> 3) & 1) << 4))) = kreg[j];
+                *reinterpret_cast<u32x4*>(Vw + (c >> 2) * VPL + kr * 64 + (c & 3) * 16) = vreg[j];
             }
         }
-        __syncthreads();
-        if (k0 + KEYS < a.Tk) fetch(k0 + KEYS);
+    };
+    fetch(0);
+    __syncthreads();       // the zero fill has landed
+    stage_write(0);
+    __syncthreads();
+    bool first = true;
+    int st = 0;
+    for (int k0 = 0; k0 < a.Tk; k0 += KEYS, st ^= 1) {
+        // tile k0 is in stage st (visible: barrier below / above); the next tile travels global -> registers while this one is
+        // multiplied and is written to the OTHER stage afterwards — every wave left that stage before the last barrier
+        const unsigned char* Kl = lds + st * STG;
+        const unsigned char* Vl = Kl + NKS * KPL;
+        if (k0 + KEYS < a.Tk && !(WI & 2)) fetch(k0 + KEYS);
 #pragma unroll
         for (int sub = 0; sub < KEYS / 32; ++sub) {
             if (k0 + sub * 32 >= a.Tk) break;
             // S^T[key][q] - m = sum_d K[key][d] Q[q][d] + (-m)
             typename F::v8 kf[NKS];   // all fragment reads first: their latencies overlap instead of queueing in front of each MFMA
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) kf[s] = *reinterpret_cast<const typename F::v8*>(Kl + s * KPL + sub * 1024 + kofs);
-            f32x16 sacc = F::mfma(kf[0], qf[0], negm);
+            for (int s = 0; s < NKS; ++s)
+                if (!(WI & 8)) kf[s] = *reinterpret_cast<const typename F::v8*>(Kl + s * KPL + sub * 1024 + kofs);
+            f32x16 sacc = negm;
+            if (!(WI & 8)) {
+                sacc = F::mfma(kf[0], qf[0], negm);
 #pragma unroll
-            for (int s = 1; s < NKS; ++s) sacc = F::mfma(kf[s], qf[s], sacc);
+                for (int s = 1; s < NKS; ++s) sacc = F::mfma(kf[s], qf[s], sacc);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = (float)(r + lane) * 0.01f + m_run;
+            }
             if (k0 + sub * 32 + 32 > a.Tk) {   // last, partial sub-tile: keys beyond Tk take no part
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -177,36 +196,38 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(A16P a) {
                     sacc[r] = key < a.Tk ? sacc[r] : -INFINITY;
                 }
             }
-            float tmax = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
-#pragma unroll
-            for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[r]), sacc[r + 1]);
-            tmax = fmaxf(tmax, sacc[15]);
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-            // the maximum moves only when some query of the wave saw a score more than 2^thr above it (always on the first tile)
-            const bool need = first || !(tmax <= a.thr);
-            if (__any(need)) {
-                const float delta = need ? tmax : 0.f;          // first tile: may be negative — m becomes the tile's maximum
-                const float corr = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
-#pragma unroll
-                for (int t = 0; t < DT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) o[t][r] *= corr;
-                l_run *= corr;
-                m_run += delta;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    negm[r] = -m_run;
-                    sacc[r] -= delta;
+            if (!(WI & 1)) {
+                float tmax = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
+    #pragma unroll
+                for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[r]), sacc[r + 1]);
+                tmax = fmaxf(tmax, sacc[15]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                // the maximum moves only when some query of the wave saw a score more than 2^thr above it (always on the first tile)
+                const bool need = first || !(tmax <= a.thr);
+                if (__any(need)) {
+                    const float delta = need ? tmax : 0.f;          // first tile: may be negative — m becomes the tile's maximum
+                    const float corr = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+    #pragma unroll
+                    for (int t = 0; t < DT; ++t)
+    #pragma unroll
+                        for (int r = 0; r < 16; ++r) o[t][r] *= corr;
+                    l_run *= corr;
+                    m_run += delta;
+    #pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        negm[r] = -m_run;
+                        sacc[r] -= delta;
+                    }
+                    first = false;
                 }
-                first = false;
+                float psum = 0.f;
+    #pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] = __builtin_amdgcn_exp2f(sacc[r]);
+                    psum += sacc[r];
+                }
+                l_run += psum;
             }
-            float psum = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                sacc[r] = __builtin_amdgcn_exp2f(sacc[r]);
-                psum += sacc[r];
-            }
-            l_run += psum;
             typename F::v8 pf[2];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
@@ -215,6 +236,10 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(A16P a) {
             // O^T[d][q] += sum_key V[key][d] P[key][q]; element j of k-step s2 is key 16 s2 + 8 (j >> 2) + 4 half + (j & 3)
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
+                if (WI & 4) {
+                    o[t][0] += (float)pf[0][0] + (float)pf[1][7];
+                    continue;
+                }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const unsigned char* vp = Vl + t * VPL + sub * 2048 + s2 * 1024 + vofs;
@@ -225,6 +250,11 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(A16P a) {
                 }
             }
         }
+        if (k0 + KEYS < a.Tk && !(WI & 2)) {
+            stage_write(st ^ 1);
+            __syncthreads();
+        }
+        if (WI & 2) st ^= 1;   // (keep reading the first tile)
     }
     if (!q_ok) return;
     const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -262,9 +292,13 @@ void launch_attn16(const A16P& p, int nks, hipStream_t s) {
 }  // namespace a16
 using namespace a16;
 
+void attention16_whatif(const Attn16Args& a, int wi, hipStream_t s);
+
 bool attention16_shape_ok(int d) { return d >= 8 && d <= 128 && d % 8 == 0; }
 
-void attention16(const Attn16Args& a, hipStream_t s) {
+void attention16(const Attn16Args& a, hipStream_t s) { attention16_whatif(a, -1, s); }
+
+void attention16_whatif(const Attn16Args& a, int wi, hipStream_t s) {
     DSD_CHECK(attention16_shape_ok(a.d), "attention16: head dim %d unsupported (multiple of 8, <= 128)", a.d);
     DSD_CHECK(a.Tk >= 1 && a.Tq >= 1, "attention16: empty sequence");
     DSD_CHECK(a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.q_hs % 8 == 0 && a.k_hs % 8 == 0 && a.v_hs % 8 == 0 && a.ldo % 4 == 0,
@@ -276,6 +310,22 @@ void attention16(const Attn16Args& a, hipStream_t s) {
     p.scale_q = a.scale_q;
     p.thr = a.thr >= 0.f ? a.thr : 8.f;
     const int nks = cdiv(a.d, 16);
+    if (wi >= 0) {   // diagnostic instantiations: fp16, head dim 64
+        DSD_CHECK(nks == 4 && !a.bf16, "attention16 what-if: fp16, head dim 64 only");
+        const dim3 grid((unsigned)(cdiv(p.Tq, 128) * p.heads * p.N)), block(256);
+        switch (wi) {
+            case 0: hipLaunchKernelGGL((attention16_kernel<_Float16, 4, 0>), grid, block, 0, s, p); break;
+            case 1: hipLaunchKernelGGL((attention16_kernel<_Float16, 4, 1>), grid, block, 0, s, p); break;
+            case 2: hipLaunchKernelGGL((attention16_kernel<_Float16, 4, 2>), grid, block, 0, s, p); break;
+            case 4: hipLaunchKernelGGL((attention16_kernel<_Float16, 4, 4>), grid, block, 0, s, p); break;
+            case 8: hipLaunchKernelGGL((attention16_kernel<_Float16, 4, 8>), grid, block, 0, s, p); break;
+            case 3: hipLaunchKernelGGL((attention16_kernel<_Float16, 4, 3>), grid, block, 0, s, p); break;
+            case 13: hipLaunchKernelGGL((attention16_kernel<_Float16, 4, 13>), grid, block, 0, s, p); break;
+            default: fail("attention16 what-if %d is not instantiated (0, 1, 2, 3, 4, 8, 13)", wi);
+        }
+        check_launch("attention16_whatif");
+        return;
+    }
     if (a.bf16) launch_attn16<__bf16>(p, nks, s); else launch_attn16<_Float16>(p, nks, s);
     check_launch("attention16");
 }

@@ -38,6 +38,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GBM = 256, GBN = 256, GBK = 64;
 constexpr int G_TILE_BYTES = GBN * GBK * 2;   // 32 KB per operand and stage
+constexpr int G_EROW = 128 * 2 + 16;          // epilogue staging: a wave's 128 n of one output row + 16 B (bank spread, 16-B aligned)
 
 template <typename T>
 struct Frag;
@@ -80,11 +81,13 @@ struct G16P {
 };
 
 // WI: what-if bits of the diagnostic instantiations (dsd_bench_gemm_half; results are then garbage): 1 no LDS-DMA staging in the
-// loop, 2 fragments read from LDS once (not per k-tile), 4 no epilogue, 8 no barrier
+// loop, 2 fragments read from LDS once (not per k-tile), 4 no epilogue, 8 no barrier,
+// 16 the output of every m tile stored over tile 0's rows (stays in L2)
 template <typename T16, int EPI, int WI = 0>
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
     using F = Frag<T16>;
-    __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * G_TILE_BYTES];   // [stage][W tile | X tile]
+    // [stage][W tile | X tile]; after the k-loop the same memory transposes the output tile (8 waves x 64 rows x 272 B)
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[(4 * G_TILE_BYTES > 8 * 64 * G_EROW) ? 4 * G_TILE_BYTES : 8 * 64 * G_EROW];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -229,16 +232,17 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
             }
         }
     } else {
-        T16* yb = reinterpret_cast<T16*>(p.y16) + (int64_t)bm0 * p.ldy;
-        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (unsigned)rows_left * (unsigned)p.ldy * 2u, 0x00020000);
+        // 16-bit output.  A lane holds 4 consecutive n (8 B) of 16 different rows: stored as they stand, every store instruction
+        // would touch 16 rows with 32 contiguous bytes each (what-if table, round 3: the epilogue was 35 % of a K = 768 launch).
+        // The wave's 128 n x 64 m sub-tile goes through LDS instead (the stages are idle now; every wave has passed the loop's
+        // last barrier): written [m][n] with ds_write_b64, read back 16 B per lane with 16 lanes along a row, so that a store
+        // instruction writes 4 rows x 256 contiguous bytes.  LDS operations of one wave execute in order: no barrier.
+        unsigned char* wb = lds + wave * (64 * G_EROW);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int m = ml + j * 16;
-            const unsigned rowoff = (unsigned)(m - bm0) * (unsigned)p.ldy * 2u;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int n = nl + i * 16;
-                const unsigned off = (m < p.M && n < p.N) ? rowoff + (unsigned)n * 2u : 0xFFFFFFF0u;
                 f32x4 v = acc[i][j] + bv[i];
                 if (EPI == 0 && n < p.qcols) v *= p.qscale;
                 typename F::v4 h;
@@ -248,8 +252,20 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) h[e] = (T16)gelu_tanh_f((float)h[e]);
                 }
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h), ry, off, 0, 0);
+                *reinterpret_cast<typename F::v4*>(wb + (j * 16 + (lane & 15)) * G_EROW + (i * 16 + (lane >> 4) * 4) * 2) = h;
             }
+        }
+        // (what-if 16: every m tile stores into the rows of tile 0 — the same instruction stream, but the output stays in L2)
+        T16* yb = reinterpret_cast<T16*>(p.y16) + ((WI & 16) ? (int64_t)0 : (int64_t)bm0 * p.ldy);
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (unsigned)rows_left * (unsigned)p.ldy * 2u, 0x00020000);
+        const int nc = bn0 + wn * 128 + (lane & 15) * 8;          // this lane's 8 columns of a row (N % 8 == 0: valid together)
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = it * 4 + (lane >> 4);
+            const int m = bm0 + wm * 64 + row;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(wb + row * G_EROW + (lane & 15) * 16);
+            const unsigned off = (m < p.M && nc < p.N) ? (unsigned)(m - bm0) * (unsigned)p.ldy * 2u + (unsigned)nc * 2u : 0xFFFFFFF0u;
+            __builtin_amdgcn_raw_buffer_store_b128(v, ry, off, 0, 0);
         }
     }
 }
@@ -325,19 +341,20 @@ void launch_gemm16_whatif(const G16P& p, int wi, hipStream_t s) {
         case 4: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 4>), g, b, 0, s, p); break;
         case 7: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 7>), g, b, 0, s, p); break;
         case 15: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 15>), g, b, 0, s, p); break;
-        default: fail("gemm16 what-if %d is not instantiated (0, 1, 2, 3, 4, 7, 15)", wi);
+        case 16: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 16>), g, b, 0, s, p); break;
+        default: fail("gemm16 what-if %d is not instantiated (0, 1, 2, 3, 4, 7, 15, 16)", wi);
     }
 }
 
 }  // namespace g16
 using namespace g16;
 
-bool gemm16_shape_ok(int M, int N, int K) { return M >= 1 && N >= 4 && K >= 8 && N % 4 == 0 && K % 8 == 0; }
+bool gemm16_shape_ok(int M, int N, int K) { return M >= 1 && N >= 8 && K >= 8 && N % 8 == 0 && K % 8 == 0; }
 
 void gemm16(const Gemm16Args& a, hipStream_t s) { gemm16_whatif(a, -1, s); }
 
 void gemm16_whatif(const Gemm16Args& a, int whatif, hipStream_t s) {
-    DSD_CHECK(gemm16_shape_ok(a.M, a.N, a.K), "gemm16: M=%d N=%d K=%d unsupported (N %% 4, K %% 8)", a.M, a.N, a.K);
+    DSD_CHECK(gemm16_shape_ok(a.M, a.N, a.K), "gemm16: M=%d N=%d K=%d unsupported (N %% 8, K %% 8)", a.M, a.N, a.K);
     DSD_CHECK(a.ldx % 8 == 0 && a.ldx >= a.K, "gemm16: ldx=%d must be a multiple of 8 and >= K", a.ldx);
     G16P p{};
     p.x = a.x; p.w = a.w; p.bias = a.bias; p.y16 = a.y16; p.x32 = a.x32; p.gate = a.gate;
@@ -349,7 +366,7 @@ void gemm16_whatif(const Gemm16Args& a, int whatif, hipStream_t s) {
     if (a.epi == EPI16_GATED) {
         DSD_CHECK(a.x32 && a.gate && a.ldx32 % 4 == 0 && a.gate_stride % 4 == 0, "gemm16: gated epilogue needs x32 / gate (strides %% 4)");
     } else {
-        DSD_CHECK(a.y16 && a.ldy % 4 == 0, "gemm16: 16-bit output missing or ldy %% 4 != 0");
+        DSD_CHECK(a.y16 && a.ldy % 8 == 0, "gemm16: 16-bit output missing or ldy %% 8 != 0 (rows are stored in 16-byte pieces)");
     }
     if (whatif >= 0) {
         launch_gemm16_whatif(p, whatif, s);

@@ -169,6 +169,7 @@ struct Attn16Args {
 };
 bool attention16_shape_ok(int d);
 void attention16(const Attn16Args& a, hipStream_t s);
+void attention16_whatif(const Attn16Args& a, int whatif, hipStream_t s);   // diagnostic instantiations (timing only), -1 = the product kernel
 
 // ---------------------------------------------------------------- misc.hip
 void timestep_embedding(const void* t, int t_is_float, int N, int dim, float* y, hipStream_t s,

@@ -361,6 +361,10 @@ int dsd_op_gemm_half(const float* x, const float* w, const float* bias, int M, i
  * LDS-DMA staging in the loop, 2 fragments read from LDS only once, 4 no epilogue, 8 no barrier; instantiated: 0, 1, 2, 3, 4,
  * 7, 15) whose results are garbage — tools/gemm_whatif.py. */
 int dsd_bench_gemm_half(int M, int N, int K, int bf16, int epi, int whatif, int iters, float* avg_ms);
+/* The same for the half-precision attention kernel on a random qkv[N,T,3C].  whatif bits: 1 no softmax arithmetic, 2 no K / V
+ * staging after the first tile, 4 no second product, 8 no first product (instantiated for fp16, head dim 64: 0, 1, 2, 3, 4, 8,
+ * 13) — tools/attn_whatif.py. */
+int dsd_bench_attention_half(int N, int T, int C, int heads, int bf16, int whatif, int iters, float* avg_ms);
 /* softmax(q k^T * d^-1/2) v of timm Attention on qkv[N,T,3C] (q | k | v, heads inside each) -> a[N,T,C], 16-bit operands,
  * fp32 softmax statistics; thr: running-maximum threshold in log2 units (< 0: the library's default). */
 int dsd_op_attention_half(const float* qkv, int N, int T, int C, int heads, int bf16, float thr, float* a, void* stream);
