@@ -205,7 +205,12 @@ class NativeModule(nn.Module):
                 self._remote.discard(nm)       # the module-side tensor was written after all: it is the truth again
                 fps.update(self._fingerprints_of([(nm, p)]))
             key = (p.data_ptr(), p._version, p.device.type, fps[nm])
-            if not force and self._uploaded.get(nm) == key:
+            old = self._uploaded.get(nm)
+            # a side without a fingerprint (CUDA-resident, or detect_data_edits switched off / on in between) compares
+            # pointer + version + device only: toggling the safety net must not by itself re-upload anything
+            if not force and old is not None and old[:3] == key[:3] and (old[3] == key[3] or old[3] == () or key[3] == ()):
+                if key[3] != ():
+                    self._uploaded[nm] = key
                 continue
             t = p.detach()
             if t.dtype != torch.float32:
@@ -240,6 +245,16 @@ class NativeModule(nn.Module):
             out[kind.value.decode()] = {"ms": ms.value, "flops": fl.value, "bytes": by.value, "calls": calls.value}
             runs = r.value
         return out, runs
+
+    def profile_ops(self):
+        """[(kind, ms, flops, bytes)] per op of the plan in launch order, for the last profiled forward."""
+        L = lib()
+        kind, ms, fl, by = C.c_char_p(), C.c_double(), C.c_double(), C.c_double()
+        out = []
+        for i in range(L.dsd_profile_op_count(self._h)):
+            check(L.dsd_profile_op_get(self._h, i, C.byref(kind), C.byref(ms), C.byref(fl), C.byref(by)))
+            out.append((kind.value.decode(), ms.value, fl.value, by.value))
+        return out
 
     def __del__(self):
         try:

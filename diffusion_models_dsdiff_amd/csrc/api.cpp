@@ -353,6 +353,19 @@ int dsd_profile_get(dsd_handle* h, int idx, const char** kind, double* total_ms,
     DSD_CATCH
 }
 
+int dsd_profile_op_count(dsd_handle* h) { return h ? (int)h->prof_op_ms.size() : -1; }
+
+int dsd_profile_op_get(dsd_handle* h, int idx, const char** kind, double* ms, double* flops, double* bytes) {
+    DSD_TRY
+    DSD_CHECK(h && idx >= 0 && idx < (int)h->prof_op_ms.size() && h->prof_op_ms.size() == h->plan.ops.size(),
+              "op index out of range (or the plan changed since the profiled forward)");
+    if (kind) *kind = h->plan.kind_names[h->plan.op_kind[idx]].c_str();
+    if (ms) *ms = h->prof_op_ms[idx];
+    if (flops) *flops = h->plan.op_flops[idx];
+    if (bytes) *bytes = h->plan.op_bytes[idx];
+    DSD_CATCH
+}
+
 int dsd_block_forward(dsd_handle* h, const float* x, int B, int C, int H, int W, const float* aux, int aux_len,
                       const float* aux2, int aux_len2, float* out, void* stream) {
     DSD_TRY
@@ -730,6 +743,27 @@ int dsd_op_group_norm(const float* x, int N, int HW, int C, const float* gamma, 
     s0.p = part.as<double>(); s0.chunks = nchunk; s0.c0 = 0; s0.c = C;
     gn_finalize(s0, GnSrc{}, N, HW, C, gamma, beta, eps, nullptr, 0, sc.as<float>(), sh.as<float>(), s);
     affine_act(x, N, HW, C, sc.as<float>(), sh.as<float>(), silu ? ACT_SILU : ACT_NONE, y, s);
+    DSD_HIP(hipStreamSynchronize(s));
+    DSD_CATCH
+}
+
+int dsd_op_gn_silu_conv_out1(const float* x, int N, int H, int W, int C, const float* gamma, const float* beta, float eps,
+                             const float* w_oihw, const float* bias, float* y, void* stream) {
+    DSD_TRY
+    hipStream_t s = (hipStream_t)stream;
+    DSD_CHECK(conv_out1_ok(C, 1, 3, 1), "gn_silu_conv_out1: %d input channels unsupported (a multiple of 64 up to 320)", C);
+    const int HW = H * W, nchunk = gn_nchunks(HW, C);
+    Tmp part((size_t)N * nchunk * C * 2 * sizeof(double)), sc((size_t)N * C * sizeof(float)), sh((size_t)N * C * sizeof(float));
+    Tmp wp((size_t)C * 9 * sizeof(float));
+    pack_ohwi(w_oihw, wp.as<float>(), 1, C, 3, s);
+    gn_stats(x, N, HW, C, part.as<double>(), nchunk, s);
+    GnSrc s0;
+    s0.p = part.as<double>(); s0.chunks = nchunk; s0.c0 = 0; s0.c = C;
+    gn_finalize(s0, GnSrc{}, N, HW, C, gamma, beta, eps, nullptr, 0, sc.as<float>(), sh.as<float>(), s);
+    ConvOut1Args a;
+    a.x = x; a.N = N; a.H = H; a.W = W; a.C = C; a.scale = sc.as<float>(); a.shift = sh.as<float>(); a.w = wp.as<float>();
+    a.bias = bias; a.y = y;
+    conv_out1(a, s);
     DSD_HIP(hipStreamSynchronize(s));
     DSD_CATCH
 }

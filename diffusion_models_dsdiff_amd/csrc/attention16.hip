@@ -19,6 +19,10 @@
 //     (a wave-uniform branch): O, l and the pending tile are then rescaled together, before any of the tile is exponentiated
 //     (cdna_hip_programming.md T13's safe order).  p <= 2^8 in the 16-bit P, sums in fp32.
 // Head dims: multiples of 8 up to 128 (padding chunks are zeroed once); keys beyond Tk are masked in the last tile.
+#include <cstdint>
+#include <cstdlib>
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace dsd {
@@ -274,9 +278,283 @@ __global__ __launch_bounds__(256, 2) void attention16_kernel(A16P a) {
         }
 }
 
+// ---- head dim 64 (every DiT size but XL): K / V by LDS-DMA, three stages --------------------------------------------------------
+// What-if table of the kernel above at 16 x 4096 tokens x 12 heads (tools/attn_whatif.py, round 3): 1294 us; without the
+// softmax arithmetic 910; WITHOUT THE STAGING (global -> registers -> ds_write, barrier) 828; with neither 634.  Staging through
+// registers costs a third of the kernel: 32 registers of loads in flight per lane, 8 ds_write_b128 per tile, and a tile that is
+// requested only ONE tile ahead of its use.  Here a tile goes global -> LDS directly (buffer_load ... lds, 16 bytes per lane, 1 KB
+// of LDS per wave-instruction, 4 instructions per wave and tile), TWO tiles ahead, behind a counted vmcnt, into a ring of three
+// 16 KB stages; still one barrier per tile.
+//   stage = K [64 keys][128 B] | V [64 keys][128 B], rows whole: 8 consecutive lanes fetch one 128-byte row of one key.
+//   K row: 16-byte chunk c stored at c ^ ((key >> 1) & 7): the A-operand read of S^T (16 consecutive lanes = 16 consecutive
+//   keys, one chunk) covers the 16 slots of the 256-byte bank row once.  V row: 64-byte half t stored at t ^ ((key >> 1) & 1):
+//   the transposed read (4 keys x 64 B per 32 lanes) covers them once as well.  Both swizzles are applied to the SOURCE
+//   address of the DMA (the LDS side of a DMA instruction is fixed: lane i -> byte 16 i of the piece).
+//   Keys beyond Tk: the lane's offset is sent out of range and the hardware delivers zeros (the scores are masked as above).
+// One LDS-DMA instruction, HIDDEN from hipcc's wait-count bookkeeping (inline asm): with the builtin, hipcc assumes every later
+// LDS read may alias a DMA still in flight and waits for the older tile at the top of each tile — the counted vmcnt below is the
+// only wait these need.  M0 (the LDS destination) is written in the same statement and restored; rsrc / soffset / M0 come from
+// readfirstlane, hence the leading s_nop (cdna_hip_programming.md "What hipcc does not do").
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ void dma16h(i32x4 rsrc, unsigned lds_addr, unsigned voff, int soff) {
+    unsigned keep;
+    asm volatile(
+        "s_nop 4\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %3\n\t"
+        "s_nop 0\n\t"
+        "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(voff), "s"(rsrc), "s"(lds_addr), "s"(soff)
+        : "memory");
+}
+static __device__ __forceinline__ i32x4 make_rsrc16(const void* base, unsigned bytes) {
+    const uint64_t b = (uint64_t)base;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));   // (stride 0, no swizzle)
+    r[2] = __builtin_amdgcn_readfirstlane((int)bytes);
+    r[3] = 0x00020000;
+    return r;
+}
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+// eight ds_read_b64_tr_b16 (d tile t = 0, 1 x k-step s2 = 0, 1 x key octet j = 0, 1) at a0 / a1 + OFF + (16 s2 + 8 j) * 128; the
+// results are NOT counted by hipcc: tr_wait8 in front of the first use
+template <int OFF>
+static __device__ __forceinline__ void tr_read8(v2i (&r)[2][2][2], unsigned a0, unsigned a1) {
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %1, %8 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %2, %8 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %3, %8 offset:%13\n\t"
+        "ds_read_b64_tr_b16 %4, %9 offset:%10\n\t"
+        "ds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
+        "ds_read_b64_tr_b16 %6, %9 offset:%12\n\t"
+        "ds_read_b64_tr_b16 %7, %9 offset:%13"
+        : "=&v"(r[0][0][0]), "=&v"(r[0][0][1]), "=&v"(r[0][1][0]), "=&v"(r[0][1][1]), "=&v"(r[1][0][0]), "=&v"(r[1][0][1]),
+          "=&v"(r[1][1][0]), "=&v"(r[1][1][1])
+        : "v"(a0), "v"(a1), "i"(OFF), "i"(OFF + 8 * 128), "i"(OFF + 16 * 128), "i"(OFF + 24 * 128)
+        : "memory");
+}
+static __device__ __forceinline__ void tr_wait8(v2i (&r)[2][2][2]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(r[0][0][0]), "+v"(r[0][0][1]), "+v"(r[0][1][0]), "+v"(r[0][1][1]), "+v"(r[1][0][0]), "+v"(r[1][0][1]),
+                   "+v"(r[1][1][0]), "+v"(r[1][1][1])
+                 :
+                 : "memory");
+}
+
+template <typename T16, int WI = 0>
+__global__ __launch_bounds__(256, 2) void attention16_dma_kernel(A16P a) {
+    using F = AF<T16>;
+    constexpr int KEYS = 64, NKS = 4, DT = 2;
+    constexpr int STG = 2 * KEYS * 128;   // K | V
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * STG];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lrow = lane & 31, half = lane >> 5;
+    const int QB = (a.Tq + 127) / 128, HB = a.heads * a.N;
+    int bid = blockIdx.x, hb, qb;
+    if ((HB & 7) == 0) {   // (placement only, as above: the query blocks of a head share an XCD)
+        const int slot = bid >> 3;
+        hb = (slot / QB) * 8 + (bid & 7);
+        qb = slot - (slot / QB) * QB;
+    } else {
+        hb = bid / QB;
+        qb = bid - hb * QB;
+    }
+    const int n = hb / a.heads, head = hb - n * a.heads;
+    const int q = qb * 128 + wave * 32 + lrow;
+    const bool q_ok = q < a.Tq;
+
+    const T16* kbase = reinterpret_cast<const T16*>(a.k) + (int64_t)n * a.Tk * a.ldk + (int64_t)head * a.k_hs;
+    const T16* vbase = reinterpret_cast<const T16*>(a.v) + (int64_t)n * a.Tk * a.ldv + (int64_t)head * a.v_hs;
+    const i32x4 rk = make_rsrc16(kbase, ((unsigned)(a.Tk - 1) * (unsigned)a.ldk + 64u) * 2u);
+    const i32x4 rv = make_rsrc16(vbase, ((unsigned)(a.Tk - 1) * (unsigned)a.ldv + 64u) * 2u);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    // this wave's four pieces of a tile: K keys 8 wave + (lane >> 3) and 32 + that, V the same keys
+    const int pkey = wave * 8 + (lane >> 3), pc = lane & 7;
+    unsigned kvo[2], vvo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int key = pkey + 32 * j;
+        kvo[j] = ((unsigned)key * (unsigned)a.ldk + 8u * (unsigned)(pc ^ ((key >> 1) & 7))) * 2u;
+        vvo[j] = ((unsigned)key * (unsigned)a.ldv + 8u * (unsigned)((((pc >> 2) ^ ((key >> 1) & 1)) << 2) | (pc & 3))) * 2u;
+    }
+    auto issue = [&](int st, int k0) {
+        const unsigned base = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + st * STG + wave * 1024));
+        const int sk = __builtin_amdgcn_readfirstlane(k0 * a.ldk * 2), sv = __builtin_amdgcn_readfirstlane(k0 * a.ldv * 2);
+        const bool tail = k0 + KEYS > a.Tk;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool ok = !tail || k0 + pkey + 32 * j < a.Tk;
+            dma16h(rk, base + j * 4096, ok ? kvo[j] : 0xFFFFFFF0u, sk);
+            dma16h(rv, base + KEYS * 128 + j * 4096, ok ? vvo[j] : 0xFFFFFFF0u, sv);
+        }
+    };
+    const int NT = (a.Tk + KEYS - 1) / KEYS;
+    issue(0, 0);
+    if (NT > 1) issue(1, KEYS);
+
+    // Q^T fragments (B operand of S^T = K Q^T): this lane's query, k-step s covers d = 16 s + 8 half .. + 8.  The scale is
+    // applied unconditionally (x 1 is exact): hipcc then waits for these loads HERE, once — left pending on one path, their
+    // vmcnt(0) lands in front of the first MFMA of the loop and waits for the tiles in flight in every iteration.
+    typename F::v8 qf[NKS];
+    {
+        const T16* qp = reinterpret_cast<const T16*>(a.q) + ((int64_t)n * a.Tq + (q_ok ? q : 0)) * a.ldq + (int64_t)head * a.q_hs;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            typename F::v8 t = *reinterpret_cast<const typename F::v8*>(qp + (2 * s + half) * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = q_ok ? (T16)((float)t[e] * a.scale_q) : (T16)0.f;
+            qf[s] = t;
+        }
+    }
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+    f32x16 negm;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+    float m_run = 0.f, l_run = 0.f;
+
+    // fragment read offsets inside a stage
+    int kofs[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) kofs[s] = lrow * 128 + (((2 * s + half) ^ ((lrow >> 1) & 7)) << 4);           // + sub * 4096
+    const int g = lane >> 4, li = lane & 15;
+    const int vkey = 4 * half + (li >> 2);                                                                       // + 32 sub + 16 s2 + 8 j
+    const int vb = (li >> 3) & 1;                                                                                // (key >> 1) & 1 of that key
+    int vofs[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) vofs[t] = KEYS * 128 + vkey * 128 + ((t ^ vb) << 6) + (16 * (g & 1) + 4 * (li & 3)) * 2;
+
+    bool first = true;
+    for (int it = 0; it < NT; ++it) {
+        const int k0 = it * KEYS;
+        // this wave's pieces of tile `it` have landed (the younger tile's four may still fly); after the barrier everybody's
+        // have, and every wave has left tile it - 1, whose stage takes tile it + 2
+        if (!(WI & 2) || it == 0) {
+            if (it + 1 < NT) __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) lgkmcnt(0)
+            else __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            if (it + 2 < NT && !(WI & 2)) issue((it + 2) % 3, k0 + 2 * KEYS);
+        }
+        const unsigned char* Sl = lds + ((WI & 2) ? 0 : (it % 3)) * STG;
+        const unsigned sl_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)const_cast<unsigned char*>(Sl);
+        auto sub_tile = [&](auto SUB) {
+            constexpr int sub = decltype(SUB)::value;
+            typename F::v8 kf[NKS];
+#pragma unroll
+            for (int s = 0; s < NKS; ++s)
+                if (!(WI & 8)) kf[s] = *reinterpret_cast<const typename F::v8*>(Sl + sub * 4096 + kofs[s]);
+            f32x16 sacc = negm;
+            if (!(WI & 8)) {
+                sacc = F::mfma(kf[0], qf[0], negm);
+#pragma unroll
+                for (int s = 1; s < NKS; ++s) sacc = F::mfma(kf[s], qf[s], sacc);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = (float)(r + lane) * 0.01f + m_run;
+            }
+            // the eight transposed V fragments of this sub-tile, requested now and waited for in front of the second product
+            // (inline asm: hipcc puts s_waitcnt vmcnt(0) in front of the ds_read_tr BUILTIN when LDS-DMA is in flight — it
+            // cannot tell the stages apart — which would serialise the tile behind the two tiles being fetched)
+            v2i vr[DT][2][2];
+            if (!(WI & 4)) tr_read8<sub * 32 * 128>(vr, sl_addr + vofs[0], sl_addr + vofs[1]);
+            if (k0 + sub * 32 + 32 > a.Tk) {   // last, partial sub-tile: keys beyond Tk take no part
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    sacc[r] = key < a.Tk ? sacc[r] : -INFINITY;
+                }
+            }
+            if (!(WI & 1)) {
+                float tmax = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
+#pragma unroll
+                for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[r]), sacc[r + 1]);
+                tmax = fmaxf(tmax, sacc[15]);
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                const bool need = first || !(tmax <= a.thr);
+                if (__any(need)) {
+                    const float delta = need ? tmax : 0.f;
+                    const float corr = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int t = 0; t < DT; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[t][r] *= corr;
+                    l_run *= corr;
+                    m_run += delta;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        negm[r] = -m_run;
+                        sacc[r] -= delta;
+                    }
+                    first = false;
+                }
+                float psum = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sacc[r] = __builtin_amdgcn_exp2f(sacc[r]);
+                    psum += sacc[r];
+                }
+                l_run += psum;
+            }
+            typename F::v8 pf[2];
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[s2][e] = (T16)sacc[8 * s2 + e];
+            if (!(WI & 4)) tr_wait8(vr);
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                if (WI & 4) {
+                    o[t][0] += (float)pf[0][0] + (float)pf[1][7];
+                    continue;
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const typename F::v8 vf = __builtin_bit_cast(typename F::v8, __builtin_shufflevector(vr[t][s2][0], vr[t][s2][1], 0, 1, 2, 3));
+                    o[t] = F::mfma(vf, pf[s2], o[t]);
+                }
+            }
+        };
+        sub_tile(std::integral_constant<int, 0>{});
+        if (k0 + 32 < a.Tk) sub_tile(std::integral_constant<int, 1>{});
+    }
+    if (!q_ok) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    T16* op = reinterpret_cast<T16*>(a.out) + ((int64_t)n * a.Tq + q) * a.ldo + (int64_t)head * a.d;
+#pragma unroll
+    for (int t = 0; t < DT; ++t)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int d = t * 32 + 8 * r4 + 4 * half;
+            typename F::v4 h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h[e] = (T16)(o[t][4 * r4 + e] * inv);
+            *reinterpret_cast<typename F::v4*>(op + d) = h;
+        }
+}
+
+// the DMA kernel takes head dim 64 with K / V addressable in 32-bit byte offsets from the (sample, head) base
+static bool attn16_dma_ok(const A16P& p) {
+    static const bool off = getenv("DSD_ATTN16_NO_DMA") != nullptr;   // A/B
+    return !off && p.d == 64 && (int64_t)p.Tk * p.ldk * 2 < (1ll << 31) && (int64_t)p.Tk * p.ldv * 2 < (1ll << 31);
+}
+
 template <typename T16>
 void launch_attn16(const A16P& p, int nks, hipStream_t s) {
     const dim3 grid((unsigned)(cdiv(p.Tq, 128) * p.heads * p.N)), block(256);
+    if (attn16_dma_ok(p)) {
+        hipLaunchKernelGGL((attention16_dma_kernel<T16>), grid, block, 0, s, p);
+        return;
+    }
     switch (nks) {
         case 1: hipLaunchKernelGGL((attention16_kernel<T16, 1>), grid, block, 0, s, p); break;
         case 2: hipLaunchKernelGGL((attention16_kernel<T16, 2>), grid, block, 0, s, p); break;
@@ -321,6 +599,10 @@ void attention16_whatif(const Attn16Args& a, int wi, hipStream_t s) {
             case 8: hipLaunchKernelGGL((attention16_kernel<_Float16, 4, 8>), grid, block, 0, s, p); break;
             case 3: hipLaunchKernelGGL((attention16_kernel<_Float16, 4, 3>), grid, block, 0, s, p); break;
             case 13: hipLaunchKernelGGL((attention16_kernel<_Float16, 4, 13>), grid, block, 0, s, p); break;
+            case 100: hipLaunchKernelGGL((attention16_dma_kernel<_Float16, 0>), grid, block, 0, s, p); break;   // 100 + bits: the LDS-DMA kernel
+            case 101: hipLaunchKernelGGL((attention16_dma_kernel<_Float16, 1>), grid, block, 0, s, p); break;
+            case 102: hipLaunchKernelGGL((attention16_dma_kernel<_Float16, 2>), grid, block, 0, s, p); break;
+            case 103: hipLaunchKernelGGL((attention16_dma_kernel<_Float16, 3>), grid, block, 0, s, p); break;
             default: fail("attention16 what-if %d is not instantiated (0, 1, 2, 3, 4, 8, 13)", wi);
         }
         check_launch("attention16_whatif");

@@ -437,13 +437,16 @@ __global__ __launch_bounds__(256) void conv_direct_lds_kernel(ConvP p) {
 // channels, keeps their K x 4 weights and bias in registers and walks over pixels: per pixel K broadcast loads, 4K FMAs and
 // one 16-byte store, no LDS and no per-element index divisions (the LDS version above reaches 1.9 TB/s, this one the
 // store rate of the elementwise kernels).
-template <int KMAX>
-__global__ __launch_bounds__(256) void conv_direct_cols_kernel(ConvP p, int W4, int ppb) {
-    const int c4n = p.Cout >> 2;
+// STATS [r3]: the workgroup's pixels are one chunk of ONE sample (ppb divides OH*OW) and it also leaves that chunk's per-channel
+// (sum, sum of squares) in stats[n][chunk][co][2] (fp64, the GnSrc layout gn_finalize reads): the GroupNorm that follows the
+// first convolution of every encoder stream no longer re-reads the 1.3 GB it just wrote.
+template <int KMAX, bool STATS>
+__global__ __launch_bounds__(256) void conv_direct_cols_kernel(ConvP p, int W4, int ppb, double* __restrict__ stats, int chunks) {
+    __shared__ double sm[STATS ? 1024 : 1][2];   // [row][co] partials of rows 1.. (rpi * Cout <= 1024)
     const int rpi = blockDim.x / W4;
     const int row = threadIdx.x / W4;
     const int c4 = threadIdx.x - row * W4;
-    if (c4 >= c4n) return;
+    double ss[4] = {0.0, 0.0, 0.0, 0.0}, qq[4] = {0.0, 0.0, 0.0, 0.0};
     float4 w[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
@@ -502,6 +505,39 @@ __global__ __launch_bounds__(256) void conv_direct_cols_kernel(ConvP p, int W4, 
             acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
         }
         *reinterpret_cast<float4*>(p.y + m * p.y_ld + c4 * 4) = acc;
+        if (STATS) {
+            const double a = acc.x, b = acc.y, c = acc.z, d = acc.w;
+            ss[0] += a; qq[0] = fma(a, a, qq[0]);
+            ss[1] += b; qq[1] = fma(b, b, qq[1]);
+            ss[2] += c; qq[2] = fma(c, c, qq[2]);
+            ss[3] += d; qq[3] = fma(d, d, qq[3]);
+        }
+    }
+    if (STATS) {   // rows 1.. hand their sums to row 0, which adds them in row order (deterministic)
+        if (row > 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sm[row * p.Cout + c4 * 4 + e][0] = ss[e];
+                sm[row * p.Cout + c4 * 4 + e][1] = qq[e];
+            }
+        }
+        __syncthreads();
+        if (row == 0) {
+            for (int r = 1; r < rpi; ++r)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    ss[e] += sm[r * p.Cout + c4 * 4 + e][0];
+                    qq[e] += sm[r * p.Cout + c4 * 4 + e][1];
+                }
+            const int64_t m0 = (int64_t)blockIdx.x * ppb;
+            const int n0 = (int)(m0 / p.ohw), chunk = (int)((m0 - (int64_t)n0 * p.ohw) / ppb);
+            double* o = stats + (((int64_t)n0 * chunks + chunk) * p.Cout + c4 * 4) * 2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[2 * e] = ss[e];
+                o[2 * e + 1] = qq[e];
+            }
+        }
     }
 }
 
@@ -623,10 +659,29 @@ size_t conv2d_scratch_bytes(const ConvArgs& a) {
     return ks > 1 ? (size_t)ks * M * a.Cout * sizeof(float) : 0;
 }
 
+// pixels per workgroup of the first-layer kernel; with_stats: a divisor of OH*OW (one chunk of one sample), 0 = none suitable
+static int direct_cols_ppb(const ConvArgs& a, int64_t M, int ohw, bool with_stats) {
+    const int W4 = a.Cout / 4, rpi = 256 / W4;
+    if (!with_stats) return std::max(rpi * 8, cdiv(cdiv(M, 8192), rpi) * rpi);
+    for (int ppb = 128; ppb >= 16; ppb >>= 1)
+        if (ohw % ppb == 0) return ppb;
+    return 0;
+}
+static bool direct_cols_ok(const ConvArgs& a) {
+    return a.Cout % 4 == 0 && a.Cout / 4 <= 256 && a.ks * a.ks * a.Cin <= 9 && !a.out_nchw && (!a.emb || a.emb_stride % 4 == 0);
+}
+
 int conv2d_stats_chunks(const ConvArgs& a) {
-    // only the split-precision implicit-GEMM kernels carry the statistics epilogue (and not their split-K form, whose
-    // output is written by the reduction kernel)
-    if (a.out_nchw || a.Cin % 4 != 0 || a.ks * a.ks * a.Cin < 32) return 0;
+    // the split-precision implicit-GEMM kernels carry the statistics epilogue (not their split-K form, whose output is
+    // written by the reduction kernel), and so does the first-layer kernel
+    if (a.Cin % 4 != 0 || a.ks * a.ks * a.Cin < 32) {
+        if (!direct_cols_ok(a)) return 0;
+        int OH, OW;
+        conv_out_hw(a, &OH, &OW);
+        const int ppb = direct_cols_ppb(a, (int64_t)a.N * OH * OW, OH * OW, true);
+        return ppb ? OH * OW / ppb : 0;
+    }
+    if (a.out_nchw) return 0;
     if (conv2d_wino_eligible(a)) return conv2d_wino_stats_chunks(a);
     int OH, OW;
     conv_out_hw(a, &OH, &OW);
@@ -723,10 +778,16 @@ void conv2d(ConvArgs a, hipStream_t s) {
 
     if (a.Cin % 4 != 0 || p.Ktot < 32) {
         const size_t lds = (size_t)p.Ktot * a.Cout * sizeof(float);
-        if (a.Cout % 4 == 0 && a.Cout / 4 <= 256 && p.Ktot <= 9 && !a.out_nchw && (!a.emb || a.emb_stride % 4 == 0)) {
+        if (direct_cols_ok(a)) {
             const int W4 = a.Cout / 4, rpi = 256 / W4;
-            const int ppb = std::max(rpi * 8, cdiv(cdiv(p.M, 8192), rpi) * rpi);
-            hipLaunchKernelGGL(conv_direct_cols_kernel<9>, dim3(cdiv(p.M, ppb)), dim3(rpi * W4), 0, s, p, W4, ppb);
+            if (a.stats) {
+                const int ppb = direct_cols_ppb(a, p.M, p.ohw, true);
+                DSD_CHECK(ppb > 0 && p.ohw / ppb == a.stats_chunks, "conv2d: statistics chunks %d do not match this launch", a.stats_chunks);
+                hipLaunchKernelGGL((conv_direct_cols_kernel<9, true>), dim3(p.M / ppb), dim3(rpi * W4), 0, s, p, W4, ppb, a.stats, a.stats_chunks);
+            } else {
+                const int ppb = direct_cols_ppb(a, p.M, p.ohw, false);
+                hipLaunchKernelGGL((conv_direct_cols_kernel<9, false>), dim3(cdiv(p.M, ppb)), dim3(rpi * W4), 0, s, p, W4, ppb, nullptr, 0);
+            }
             check_launch("conv_direct_cols");
         } else if (a.Cout % 4 == 0 && lds <= 60 * 1024) {
             hipLaunchKernelGGL(conv_direct_lds_kernel, dim3(cdiv(p.M, 64)), dim3(256), lds, s, p);

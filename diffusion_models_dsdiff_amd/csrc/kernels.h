@@ -56,6 +56,19 @@ inline void conv_out_hw(const ConvArgs& a, int* OH, int* OW) {
 // chunks per sample the kernel conv2d() will launch for these arguments can emit output statistics with (0 = it cannot:
 // the caller runs gn_stats on the output instead)
 int conv2d_stats_chunks(const ConvArgs& a);
+// out = Conv3x3(SiLU(x * scale + shift)) with ONE output channel (conv_out1.hip): x NHWC [N,H,W,C] BEFORE the normalisation,
+// scale / shift = gn_finalize's coefficients [N][C], w = [3][3][C] (the packed OHWI weight of a 1-channel conv), y = [N,H,W]
+struct ConvOut1Args {
+    const float* x = nullptr;
+    int N = 0, H = 0, W = 0, C = 0;
+    const float* scale = nullptr;
+    const float* shift = nullptr;
+    const float* w = nullptr;
+    const float* bias = nullptr;
+    float* y = nullptr;
+};
+bool conv_out1_ok(int C, int cout, int ks, int stride);
+void conv_out1(const ConvOut1Args& a, hipStream_t s);
 enum { PREC_F32 = 0, PREC_BF16X3 = 1, PREC_BF16X6 = 2, PREC_F16X3 = 3, PREC_F16 = 4, PREC_BF16 = 5 };
 void conv2d(ConvArgs a, hipStream_t s);
 // conv_split.hip: fp32 operands as sums of bf16 pieces on the bf16 matrix cores

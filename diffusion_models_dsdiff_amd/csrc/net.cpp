@@ -978,6 +978,40 @@ struct Builder {
         release_raw(g.scoff, g.sbytes);
         release_raw(g.shoff, g.sbytes);
     }
+    // out = Conv3x3(SiLU(GroupNorm(x))) with one output channel written to the caller's buffer: one memory-bound pass
+    // (conv_out1.hip) when the shape allows and the GroupNorm fusion is on, else normalisation pass + generic convolution
+    void out_conv1(const std::string& norm, const std::string& cv, const Tn& x, int cout) {
+        if (!(hd->fuse_gn_apply && conv_out1_ok(x.c, cout, 3, 1) && !gn_small_ok(x.hw(), x.c))) {
+            Tn a = gn_act(norm, x, ACT_SILU);
+            conv(cv, a, cout, 3, 1, false, nullptr, nullptr, -1, /*to_out=*/true);
+            release(a);
+            return;
+        }
+        const Param& pw = hd->PP(cv + ".weight");
+        DSD_CHECK(pw.numel == (int64_t)9 * x.c, "conv %s: weight has %lld elements, graph expects 1x%dx3x3", cv.c_str(),
+                  (long long)pw.numel, x.c);
+        GnRef g = gn_prepare(norm, x, ACT_SILU);
+        const float* w = W(cv + ".weight");
+        const float* bias = W(cv + ".bias");
+        const size_t xoff = x.off, scoff = g.scoff, shoff = g.shoff;
+        const int N = x.n, H = x.h, Wd = x.w, C = x.c;
+        dsd_handle* h = hd;
+        const double fl = 2.0 * N * H * Wd * 9.0 * C;
+        plan.flops += fl;
+        op([=](hipStream_t s) {
+            ConvOut1Args a;
+            a.x = reinterpret_cast<const float*>(h->arena + xoff);
+            a.N = N; a.H = H; a.W = Wd; a.C = C;
+            a.scale = reinterpret_cast<const float*>(h->arena + scoff);
+            a.shift = reinterpret_cast<const float*>(h->arena + shoff);
+            a.w = w;
+            a.bias = bias;
+            a.y = h->io.out;
+            conv_out1(a, s);
+        }, 1, "gn_silu_conv_out1", fl, 4.0 * N * H * Wd * (C + 1.0));
+        gn_release(g);
+    }
+
     // would conv(name, x, cout, 3) apply the GroupNorm + SiLU of its input by itself?  (the tap-reuse kernel, bf16x6 only)
     bool can_fuse_gn(const Tn& x, int cout) {
         if (!hd->fuse_gn_apply || conv_prec() != PREC_BF16X6 || x.c % 32 != 0) return false;
@@ -1579,10 +1613,8 @@ void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats, bool 
         }
     }
     // ---- out = Conv3x3(SiLU(GN(h)))  (model.py:511-515,751)
-    Tn a = b.gn_act("out.0", h, ACT_SILU);
+    b.out_conv1("out.0", "out.2", h, cfg.out_channels);
     b.release(h);
-    b.conv("out.2", a, cfg.out_channels, 3, 1, false, nullptr, nullptr, -1, /*to_out=*/true);
-    b.release(a);
     b.release(emb_all);
 }
 
@@ -2189,9 +2221,11 @@ void dsd::net_run(dsd_handle* h, hipStream_t s) {
         h->prof_calls.assign(p.kind_names.size(), 0);
         h->prof_runs = 0;
     }
+    h->prof_op_ms.assign(n, 0.f);
     for (size_t i = 0; i < n; ++i) {
         float ms = 0.f;
         DSD_HIP(hipEventElapsedTime(&ms, h->ev[2 * i], h->ev[2 * i + 1]));
+        h->prof_op_ms[i] = ms;
         const int k = p.op_kind[i];
         h->prof_ms[k] += ms;
         h->prof_flops[k] += p.op_flops[i];

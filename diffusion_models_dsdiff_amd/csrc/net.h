@@ -172,6 +172,7 @@ struct dsd_handle {
     std::vector<hipEvent_t> ev;
     std::vector<double> prof_ms, prof_flops, prof_bytes;   // per kind
     std::vector<int64_t> prof_calls;
+    std::vector<float> prof_op_ms;                         // per op of the plan, last profiled forward
     std::vector<std::string> prof_names;
     int prof_runs = 0;
     size_t tbuf_cap = 0, mout_cap = 0, zplane_cap = 0, dpm_m_cap = 0;

@@ -46,6 +46,15 @@ def group_norm(x_nhwc, gamma, beta, eps=1e-5, silu=False):
     return y
 
 
+def gn_silu_conv_out1(x_nhwc, gamma, beta, w_oihw, bias, eps=1e-5):
+    """The U-Net's `out` layer in one pass: Conv3x3(SiLU(GroupNorm32(x))) -> [N, H, W] (one output channel)."""
+    N, H, W, Cc = x_nhwc.shape
+    y = torch.empty((N, H, W), device=x_nhwc.device, dtype=torch.float32)
+    check(lib().dsd_op_gn_silu_conv_out1(dptr(x_nhwc), N, H, W, Cc, dptr(gamma), dptr(beta), eps, dptr(w_oihw.contiguous()),
+                                         dptr(bias), dptr(y), stream_ptr()))
+    return y
+
+
 def qkv_attention(qkv_ntc, heads, new_order=True, split=False):
     """split: bf16x6 arithmetic (operands as 3 bf16 pieces, 6 products) instead of the fp32 matrix cores."""
     N, T, C3 = qkv_ntc.shape

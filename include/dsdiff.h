@@ -169,6 +169,9 @@ int dsd_profile_enable(dsd_handle* h, int on);
 int dsd_profile_count(dsd_handle* h);
 int dsd_profile_get(dsd_handle* h, int idx, const char** kind, double* total_ms, double* flops, double* bytes,
                     int64_t* calls, int* runs);
+/* The same per op of the plan, in launch order, for the last profiled forward (kind = the op's kernel kind). */
+int dsd_profile_op_count(dsd_handle* h);
+int dsd_profile_op_get(dsd_handle* h, int idx, const char** kind, double* ms, double* flops, double* bytes);
 
 /* ---- sampling loop ----------------------------------------------------------------------- */
 /* Whole-forward hipGraph replay inside dsd_sample / dsd_sample_dpm (OFF by default): the network evaluation of a step is
@@ -346,6 +349,10 @@ int dsd_conv_plan(int N, int H, int W, int Cin, int Cout, int ks, int stride, in
 /* GroupNorm(32, C, eps) [+ SiLU] on x[N,HW,C]. */
 int dsd_op_group_norm(const float* x, int N, int HW, int C, const float* gamma, const float* beta, float eps,
                       int silu, float* y, void* stream);
+/* The model's last layer as one pass: y[N,H,W] = Conv3x3(SiLU(GroupNorm32(x))) with ONE output channel, x NHWC [N,H,W,C],
+ * C a multiple of 64 up to 320, w_oihw [1,C,3,3] (UNet_DS_Diff/model.py:511-515 `self.out`, applied at :751). */
+int dsd_op_gn_silu_conv_out1(const float* x, int N, int H, int W, int C, const float* gamma, const float* beta, float eps,
+                             const float* w_oihw, const float* bias, float* y, void* stream);
 /* QKVAttention / QKVAttentionLegacy (openaimodel.py:496-555) on qkv[N,T,3C] -> a[N,T,C].  split = 0: both products on
  * the fp32 matrix cores (what DSD_PREC_F32 runs); 1: operands split exactly into three bf16 pieces, six bf16 MFMA products
  * each (what every other mode runs); the softmax is fp32 either way. */

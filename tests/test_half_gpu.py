@@ -77,7 +77,11 @@ def attn64(qkv, heads, dt):
 
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 @pytest.mark.parametrize("N,T,C,heads", [(2, 64, 64, 4), (2, 64, 96, 3), (1, 1024, 768, 12), (2, 100, 144, 2), (1, 333, 128, 1),
-                                          (1, 4096, 128, 2), (3, 31, 48, 2), (1, 200, 48, 6)])
+                                          (1, 4096, 128, 2), (3, 31, 48, 2), (1, 200, 48, 6),
+                                          # head dim 64 = the LDS-DMA kernel (three-stage ring): one, two, three and many tiles,
+                                          # ragged last tiles (keys beyond Tk come as out-of-range DMA lanes), query blocks < 128
+                                          (3, 31, 128, 2), (1, 64, 64, 1), (1, 65, 64, 1), (2, 100, 128, 2), (1, 129, 192, 3),
+                                          (2, 200, 64, 1), (1, 333, 64, 1), (1, 1000, 128, 2)])
 def test_attention_half_vs_fp64(dt, N, T, C, heads):
     from diffusion_models_dsdiff_amd import ops
     qkv = randn((N, T, 3 * C), 11)

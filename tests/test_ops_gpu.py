@@ -224,6 +224,29 @@ def test_group_norm_vs_oracle(ops, shape, silu):
     assert rel_l2(ops.to_nchw(y), ref) < 2e-6
 
 
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 37, 45), (1, 128, 16, 32), (3, 192, 5, 7), (2, 256, 33, 64), (2, 320, 64, 64),
+                                     (1, 320, 256, 256)])
+def test_gn_silu_conv_out1_vs_fp64(ops, N, C, H, W):
+    """The network's last layer (GroupNorm32 + SiLU + Conv3x3 to ONE channel, model.py:511-515) as one memory-bound pass
+    (conv_out1.hip): tile edges (sizes that are no multiples of the 16 x 32 tile), every channel count it takes, the headline
+    size.  fp32 FMAs, hardware exp2 / reciprocal in the SiLU: <= 2e-6 of the float64 evaluation."""
+    g = torch.Generator().manual_seed(C + H)
+    x = torch.randn(N, C, H, W, generator=g) * 2 + 0.5
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    w, b = torch.randn(1, C, 3, 3, generator=g) / (3 * C ** 0.5), torch.randn(1, generator=g)
+    ref = F.conv2d(F.silu(F.group_norm(x.double(), 32, gamma.double(), beta.double(), 1e-5)), w.double(), b.double(), padding=1)
+    y = ops.gn_silu_conv_out1(cu(ops.to_nhwc(x)), cu(gamma), cu(beta), cu(w), cu(b))
+    err = rel_l2(y.unsqueeze(1), ref)
+    print(f"gn_silu_conv_out1 N={N} C={C} {H}x{W}: rel-L2 vs fp64 {err:.3e}")
+    assert err < 2e-6
+
+
+def test_gn_silu_conv_out1_refuses_other_widths(ops):
+    x = torch.zeros(1, 8, 8, 96).cuda()
+    with pytest.raises(RuntimeError, match="input channels unsupported"):
+        ops.gn_silu_conv_out1(x, torch.ones(96).cuda(), torch.zeros(96).cuda(), torch.zeros(1, 96, 3, 3).cuda(), torch.zeros(1).cuda())
+
+
 def test_group_norm_golden(ops):
     g = golden("ops")
     for key, xs, shp, sc, of in [("gn_silu_320", 11, (2, 320, 16, 16), 2.0, 0.5), ("gn_silu_960", 12, (2, 960, 8, 8), 3.0, -1.0)]:
@@ -321,7 +344,9 @@ def test_diagnostic_entry_points():
         assert ms.value > 0 and 300.0 < tf.value < 2600.0, (v, ms.value, tf.value)
     assert rates[2] > rates[0] > 0.9 * rates[1]      # zeros hold a higher clock; LDS-fed is not faster than register-fed
     ms, tf = C.c_float(), C.c_double()
-    assert L.dsd_bench_mfma_peak(7, 4, 2.0, 3, C.byref(ms), C.byref(tf)) != 0
+    _lib.check(L.dsd_bench_mfma_peak(4, 4, 2.0, 3, C.byref(ms), C.byref(tf)))       # round 3: variants 4-7 = the 16x16x32 shape
+    assert 300.0 < tf.value < 2600.0
+    assert L.dsd_bench_mfma_peak(8, 4, 2.0, 3, C.byref(ms), C.byref(tf)) != 0       # beyond the table: refused
     import numpy as np
     buf = np.zeros((512, 8), dtype=np.int64)
     n = C.c_int()
