@@ -346,16 +346,17 @@ static __device__ __forceinline__ void tr_wait8(v2i (&r)[2][2][2]) {
                  : "memory");
 }
 
-template <typename T16, int WI = 0>
-__global__ __launch_bounds__(256, 2) void attention16_dma_kernel(A16P a) {
+// NW waves (4 or 8) of 32 queries share the stages: 8 waves = 256 queries per workgroup halve the K / V bytes and barriers per FLOP
+template <typename T16, int WI = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention16_dma_kernel(A16P a) {
     using F = AF<T16>;
-    constexpr int KEYS = 64, NKS = 4, DT = 2;
+    constexpr int KEYS = 64, NKS = 4, DT = 2, QPB = 32 * NW, PJ = 8 / NW;   // queries per block; K (and V) pieces per wave and tile
     constexpr int STG = 2 * KEYS * 128;   // K | V
     __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * STG];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int lrow = lane & 31, half = lane >> 5;
-    const int QB = (a.Tq + 127) / 128, HB = a.heads * a.N;
+    const int QB = (a.Tq + QPB - 1) / QPB, HB = a.heads * a.N;
     int bid = blockIdx.x, hb, qb;
     if ((HB & 7) == 0) {   // (placement only, as above: the query blocks of a head share an XCD)
         const int slot = bid >> 3;
@@ -366,7 +367,7 @@ __global__ __launch_bounds__(256, 2) void attention16_dma_kernel(A16P a) {
         qb = bid - hb * QB;
     }
     const int n = hb / a.heads, head = hb - n * a.heads;
-    const int q = qb * 128 + wave * 32 + lrow;
+    const int q = qb * QPB + wave * 32 + lrow;
     const bool q_ok = q < a.Tq;
 
     const T16* kbase = reinterpret_cast<const T16*>(a.k) + (int64_t)n * a.Tk * a.ldk + (int64_t)head * a.k_hs;
@@ -376,9 +377,9 @@ __global__ __launch_bounds__(256, 2) void attention16_dma_kernel(A16P a) {
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
     // this wave's four pieces of a tile: K keys 8 wave + (lane >> 3) and 32 + that, V the same keys
     const int pkey = wave * 8 + (lane >> 3), pc = lane & 7;
-    unsigned kvo[2], vvo[2];
+    unsigned kvo[PJ], vvo[PJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < PJ; ++j) {
         const int key = pkey + 32 * j;
         kvo[j] = ((unsigned)key * (unsigned)a.ldk + 8u * (unsigned)(pc ^ ((key >> 1) & 7))) * 2u;
         vvo[j] = ((unsigned)key * (unsigned)a.ldv + 8u * (unsigned)((((pc >> 2) ^ ((key >> 1) & 1)) << 2) | (pc & 3))) * 2u;
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void attention16_dma_kernel(A16P a) {
         const int sk = __builtin_amdgcn_readfirstlane(k0 * a.ldk * 2), sv = __builtin_amdgcn_readfirstlane(k0 * a.ldv * 2);
         const bool tail = k0 + KEYS > a.Tk;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < PJ; ++j) {
             const bool ok = !tail || k0 + pkey + 32 * j < a.Tk;
             dma16h(rk, base + j * 4096, ok ? kvo[j] : 0xFFFFFFF0u, sk);
             dma16h(rv, base + KEYS * 128 + j * 4096, ok ? vvo[j] : 0xFFFFFFF0u, sv);
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(256, 2) void attention16_dma_kernel(A16P a) {
         // this wave's pieces of tile `it` have landed (the younger tile's four may still fly); after the barrier everybody's
         // have, and every wave has left tile it - 1, whose stage takes tile it + 2
         if (!(WI & 2) || it == 0) {
-            if (it + 1 < NT) __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) lgkmcnt(0)
+            if (it + 1 < NT) __builtin_amdgcn_s_waitcnt(NW == 4 ? 0x0074 : 0x0072);   // vmcnt(2 PJ) lgkmcnt(0)
             else __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
             if (it + 2 < NT && !(WI & 2)) issue((it + 2) % 3, k0 + 2 * KEYS);
@@ -552,7 +553,11 @@ template <typename T16>
 void launch_attn16(const A16P& p, int nks, hipStream_t s) {
     const dim3 grid((unsigned)(cdiv(p.Tq, 128) * p.heads * p.N)), block(256);
     if (attn16_dma_ok(p)) {
-        hipLaunchKernelGGL((attention16_dma_kernel<T16>), grid, block, 0, s, p);
+        static const bool w8 = getenv("DSD_ATTN16_W8") != nullptr;   // A/B: 8 waves = 256 queries per workgroup
+        if (w8 && p.Tq >= 256)
+            hipLaunchKernelGGL((attention16_dma_kernel<T16, 0, 8>), dim3((unsigned)(cdiv(p.Tq, 256) * p.heads * p.N)), dim3(512), 0, s, p);
+        else
+            hipLaunchKernelGGL((attention16_dma_kernel<T16>), grid, block, 0, s, p);
         return;
     }
     switch (nks) {
@@ -603,6 +608,8 @@ void attention16_whatif(const Attn16Args& a, int wi, hipStream_t s) {
             case 101: hipLaunchKernelGGL((attention16_dma_kernel<_Float16, 1>), grid, block, 0, s, p); break;
             case 102: hipLaunchKernelGGL((attention16_dma_kernel<_Float16, 2>), grid, block, 0, s, p); break;
             case 103: hipLaunchKernelGGL((attention16_dma_kernel<_Float16, 3>), grid, block, 0, s, p); break;
+            case 200: hipLaunchKernelGGL((attention16_dma_kernel<_Float16, 0, 8>), dim3((unsigned)(cdiv(p.Tq, 256) * p.heads * p.N)), dim3(512), 0, s, p); break;   // 8 waves
+            case 202: hipLaunchKernelGGL((attention16_dma_kernel<_Float16, 2, 8>), dim3((unsigned)(cdiv(p.Tq, 256) * p.heads * p.N)), dim3(512), 0, s, p); break;
             default: fail("attention16 what-if %d is not instantiated (0, 1, 2, 3, 4, 8, 13)", wi);
         }
         check_launch("attention16_whatif");

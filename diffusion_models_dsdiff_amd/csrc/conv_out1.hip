@@ -35,8 +35,10 @@ __device__ __forceinline__ float silu_f(float v) {
     return v * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v));
 }
 
+// (3 workgroups per CU: without the register cap hipcc keeps all 9 x C / 16 weight registers of a lane resident — 370 VGPRs at
+// C = 320, one wave per SIMD and nothing to hide the loads behind: 619 us at the headline size against the 270 us of the read)
 template <int NJ>   // C = 64 * NJ
-__global__ __launch_bounds__(256) void conv_out1_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+__global__ __launch_bounds__(256, 3) void conv_out1_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                         const float* __restrict__ shift, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int H, int W,
                                                         int tiles_x, int tiles_y) {
@@ -74,6 +76,8 @@ __global__ __launch_bounds__(256) void conv_out1_kernel(const float* __restrict_
 #pragma unroll
             for (int j = 0; j < NJ; ++j) v[u][j] = *reinterpret_cast<const float4*>(px + 64 * j);
         }
+        int wlane = l16;                     // opaque per trip: the weight reads stay LDS reads inside the loop (hoisted, they
+        asm volatile("" : "+v"(wlane));      // are 9 x C / 16 registers per lane and spill)
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float acc[9];
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_out1_kernel(const float* __restrict_
                 a.w = silu_f(fmaf(v[u][j].w, sc[j].w, sh[j].w));
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
-                    const float4 wk = wl[k * (C / 4) + 16 * j + l16];
+                    const float4 wk = wl[k * (C / 4) + 16 * j + wlane];
                     acc[k] = fmaf(a.x, wk.x, acc[k]);
                     acc[k] = fmaf(a.y, wk.y, acc[k]);
                     acc[k] = fmaf(a.z, wk.z, acc[k]);

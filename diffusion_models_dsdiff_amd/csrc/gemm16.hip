@@ -81,7 +81,7 @@ struct G16P {
 };
 
 // WI: what-if bits of the diagnostic instantiations (dsd_bench_gemm_half; results are then garbage): 1 no LDS-DMA staging in the
-// loop, 2 fragments read from LDS once (not per k-tile), 4 no epilogue, 8 no barrier,
+// loop, 2 fragments read from LDS once (not per k-tile), 4 no epilogue, 8 no barrier, 32 the DMA is issued but never waited for (barrier only),
 // 16 the output of every m tile stored over tile 0's rows (stays in L2)
 template <typename T16, int EPI, int WI = 0>
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
@@ -179,7 +179,12 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
                 for (int j = 0; j < 4; ++j) acc[i][j] = F::mfma(af[ks][i], bf[ks][j], acc[i][j]);
             __builtin_amdgcn_s_setprio(0);
         }
-        if (!(WI & 8)) __syncthreads();   // vmcnt(0) + barrier: tile t+1 has landed, every wave is done reading tile t
+        if (WI & 32) {   // (diagnostic) barrier WITHOUT the wait for the DMA: what the exposed latency of the next tile costs
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0) only
+            __builtin_amdgcn_s_barrier();
+        } else if (!(WI & 8)) {
+            __syncthreads();   // vmcnt(0) + barrier: tile t+1 has landed, every wave is done reading tile t
+        }
     }
     if (WI & 4) {   // (diagnostic) keep the accumulators alive without the stores
         float t = 0.f;
@@ -342,7 +347,8 @@ void launch_gemm16_whatif(const G16P& p, int wi, hipStream_t s) {
         case 7: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 7>), g, b, 0, s, p); break;
         case 15: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 15>), g, b, 0, s, p); break;
         case 16: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 16>), g, b, 0, s, p); break;
-        default: fail("gemm16 what-if %d is not instantiated (0, 1, 2, 3, 4, 7, 15, 16)", wi);
+        case 32: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 32>), g, b, 0, s, p); break;
+        default: fail("gemm16 what-if %d is not instantiated (0, 1, 2, 3, 4, 7, 15, 16, 32)", wi);
     }
 }
 

@@ -9,7 +9,8 @@ _lib.require_gpu(0)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 NAMES = {-1: "product", 0: "diag build, nothing removed", 1: "no softmax arithmetic", 2: "no K/V staging in the loop", 3: "no softmax, no staging",
          4: "no P V product", 8: "no Q K^T product", 13: "softmax arithmetic + staging only",
-         100: "LDS-DMA kernel", 101: "LDS-DMA, no softmax arithmetic", 102: "LDS-DMA, no staging in the loop", 103: "LDS-DMA, neither"}
+         100: "LDS-DMA kernel", 101: "LDS-DMA, no softmax arithmetic", 102: "LDS-DMA, no staging in the loop", 103: "LDS-DMA, neither",
+         200: "LDS-DMA, 8 waves (256 queries)", 202: "LDS-DMA, 8 waves, no staging in the loop"}
 N, T, Cc, H = 16, 4096, 768, 12
 fl = 4.0 * N * H * T * T * (Cc // H)
 res = {w: [] for w in NAMES}
