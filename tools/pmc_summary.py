@@ -21,8 +21,8 @@ meta = {"precision": sys.argv[5] if len(sys.argv) > 5 else "bf16x6", "git_head":
 
 def demangle(name):
     """rocprofv3 leaves kernels whose template arguments are _Float16 / __bf16 mangled (and the image has no llvm-cxxfilt):
-    spell the few such symbols of this library out — _ZN3dsd3g1613gemm16_kernelIDF16_Li2EEEvNS0_4G16PE ->
-    dsd::g16::gemm16_kernel<_Float16, 2>."""
+    spell the few such symbols of this library out — _ZN3dsd3g1613gemm16_kernelIDF16_Li2ELi0EEEvNS0_4G16PE ->
+    dsd::g16::gemm16_kernel<_Float16, 2, 0>."""
     import re
     if not name.startswith("_ZN"):
         return name
@@ -34,10 +34,11 @@ def demangle(name):
         n = int(name[i:j])
         parts.append(name[j:j + n])
         i = j + n
-    m = re.match(r"I(DF16_|DF16b)(?:Li(\d+)E)?E", name[i:])
+    m = re.match(r"I(DF16_|DF16b)((?:Li\d+E)*)E", name[i:])
     if not parts or not m:
         return name
-    return "::".join(parts) + f"<{'_Float16' if m.group(1) == 'DF16_' else '__bf16'}{', ' + m.group(2) if m.group(2) is not None else ''}>"
+    ints = re.findall(r"Li(\d+)E", m.group(2))
+    return "::".join(parts) + "<" + ", ".join(["_Float16" if m.group(1) == "DF16_" else "__bf16"] + ints) + ">"
 
 
 def load(path):

@@ -58,7 +58,7 @@ def kernel_symbol(kind: str):
     if kind.startswith("gemm16"):
         return "gemm16_kernel"
     if kind == "attention16":
-        return "attention16_kernel"
+        return "attention16_"          # attention16_kernel<..> / attention16_dma_kernel<..> (head dim 64)
     if kind == "attention":
         return "attention_split_kernel"
     if kind.startswith("conv_bf16x6"):
