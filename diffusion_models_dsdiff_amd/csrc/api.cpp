@@ -859,6 +859,7 @@ int dsd_bench_attention_half(int N, int T, int C, int heads, int bf16, int whati
     a.v = (const char*)q16.p + (size_t)2 * C * 2;
     a.bf16 = bf16;
     a.out = o16.p;
+    a.scale_q = 1.4426950408889634f / std::sqrt((float)d);   // scores of unit variance in base 2, as the qkv GEMM's epilogue leaves them
     attention16_whatif(a, whatif, s);
     hipEvent_t e0, e1;
     DSD_HIP(hipEventCreate(&e0));

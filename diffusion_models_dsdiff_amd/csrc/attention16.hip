@@ -346,11 +346,16 @@ static __device__ __forceinline__ void tr_wait8(v2i (&r)[2][2][2]) {
                  : "memory");
 }
 
-// NW waves (4 or 8) of 32 queries share the stages: 8 waves = 256 queries per workgroup halve the K / V bytes and barriers per FLOP
-template <typename T16, int WI = 0, int NW = 4>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention16_dma_kernel(A16P a) {
+// NW waves (4 or 8) share the stages, each wave owns QW blocks of 32 queries (1 or 2).  8 waves = 256 queries per workgroup halve
+// the K / V bytes and barriers per FLOP: SLOWER (1185 vs 1045 us) while the kernel needed 146 registers — one workgroup per CU,
+// nobody runs while eight waves meet at the barrier — and the FASTEST variant (886 vs 977 us) once it fitted 128 registers and two
+// such workgroups share a CU: the product configuration.  QW = 2 gets the same 256 queries from FOUR waves (a K / V fragment is
+// read from LDS once and multiplied with two query blocks; two independent MFMA chains and softmax streams per wave; 228
+// registers): 944 us, between the two.
+template <typename T16, int WI = 0, int NW = 4, int QW = 1>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attention16_dma_kernel(A16P a) {   // (second argument = waves per SIMD: 8 waves in 128 registers, two workgroups per CU)
     using F = AF<T16>;
-    constexpr int KEYS = 64, NKS = 4, DT = 2, QPB = 32 * NW, PJ = 8 / NW;   // queries per block; K (and V) pieces per wave and tile
+    constexpr int KEYS = 64, NKS = 4, DT = 2, QPB = 32 * NW * QW, PJ = 8 / NW;   // queries per block; K (and V) pieces per wave and tile
     constexpr int STG = 2 * KEYS * 128;   // K | V
     __shared__ __attribute__((aligned(1024))) unsigned char lds[3 * STG];
 
@@ -367,15 +372,20 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention16_dma_kern
         qb = bid - hb * QB;
     }
     const int n = hb / a.heads, head = hb - n * a.heads;
-    const int q = qb * QPB + wave * 32 + lrow;
-    const bool q_ok = q < a.Tq;
+    int q[QW];
+    bool q_ok[QW];
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+        q[w] = qb * QPB + (wave * QW + w) * 32 + lrow;
+        q_ok[w] = q[w] < a.Tq;
+    }
 
     const T16* kbase = reinterpret_cast<const T16*>(a.k) + (int64_t)n * a.Tk * a.ldk + (int64_t)head * a.k_hs;
     const T16* vbase = reinterpret_cast<const T16*>(a.v) + (int64_t)n * a.Tk * a.ldv + (int64_t)head * a.v_hs;
     const i32x4 rk = make_rsrc16(kbase, ((unsigned)(a.Tk - 1) * (unsigned)a.ldk + 64u) * 2u);
     const i32x4 rv = make_rsrc16(vbase, ((unsigned)(a.Tk - 1) * (unsigned)a.ldv + 64u) * 2u);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    // this wave's four pieces of a tile: K keys 8 wave + (lane >> 3) and 32 + that, V the same keys
+    // this wave's pieces of a tile: K keys 8 wave + (lane >> 3) (+ 32 with four waves), V the same keys
     const int pkey = wave * 8 + (lane >> 3), pc = lane & 7;
     unsigned kvo[PJ], vvo[PJ];
 #pragma unroll
@@ -402,26 +412,31 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention16_dma_kern
     // Q^T fragments (B operand of S^T = K Q^T): this lane's query, k-step s covers d = 16 s + 8 half .. + 8.  The scale is
     // applied unconditionally (x 1 is exact): hipcc then waits for these loads HERE, once — left pending on one path, their
     // vmcnt(0) lands in front of the first MFMA of the loop and waits for the tiles in flight in every iteration.
-    typename F::v8 qf[NKS];
-    {
-        const T16* qp = reinterpret_cast<const T16*>(a.q) + ((int64_t)n * a.Tq + (q_ok ? q : 0)) * a.ldq + (int64_t)head * a.q_hs;
+    typename F::v8 qf[QW][NKS];
+#pragma unroll
+    for (int w = 0; w < QW; ++w) {
+        const T16* qp = reinterpret_cast<const T16*>(a.q) + ((int64_t)n * a.Tq + (q_ok[w] ? q[w] : 0)) * a.ldq + (int64_t)head * a.q_hs;
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
             typename F::v8 t = *reinterpret_cast<const typename F::v8*>(qp + (2 * s + half) * 8);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = q_ok ? (T16)((float)t[e] * a.scale_q) : (T16)0.f;
-            qf[s] = t;
+            for (int e = 0; e < 8; ++e) t[e] = q_ok[w] ? (T16)((float)t[e] * a.scale_q) : (T16)0.f;
+            qf[w][s] = t;
         }
     }
-    f32x16 o[DT];
+    f32x16 o[QW][DT];
+    f32x16 negm[QW];
+    float m_run[QW], l_run[QW];
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int w = 0; w < QW; ++w) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-    f32x16 negm;
+        for (int t = 0; t < DT; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) negm[r] = 0.f;
-    float m_run = 0.f, l_run = 0.f;
+            for (int r = 0; r < 16; ++r) o[w][t][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[w][r] = 0.f;
+        m_run[w] = l_run[w] = 0.f;
+    }
 
     // fragment read offsets inside a stage
     int kofs[NKS];
@@ -435,9 +450,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention16_dma_kern
     for (int t = 0; t < DT; ++t) vofs[t] = KEYS * 128 + vkey * 128 + ((t ^ vb) << 6) + (16 * (g & 1) + 4 * (li & 3)) * 2;
 
     bool first = true;
+    const float pbound = 16.f * __builtin_amdgcn_exp2f(fminf(a.thr, 11.f));   // (2^15 at most: P is 16-bit)
     for (int it = 0; it < NT; ++it) {
         const int k0 = it * KEYS;
-        // this wave's pieces of tile `it` have landed (the younger tile's four may still fly); after the barrier everybody's
+        // this wave's pieces of tile `it` have landed (the younger tile's may still fly); after the barrier everybody's
         // have, and every wave has left tile it - 1, whose stage takes tile it + 2
         if (!(WI & 2) || it == 0) {
             if (it + 1 < NT) __builtin_amdgcn_s_waitcnt(NW == 4 ? 0x0074 : 0x0072);   // vmcnt(2 PJ) lgkmcnt(0)
@@ -449,98 +465,144 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void attention16_dma_kern
         const unsigned sl_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)const_cast<unsigned char*>(Sl);
         auto sub_tile = [&](auto SUB) {
             constexpr int sub = decltype(SUB)::value;
-            typename F::v8 kf[NKS];
+            // scores of this sub-tile minus the running maximum: S^T[key][q] - m = sum_d K[key][d] Q[q][d] + (-m); keys beyond Tk -> -inf
+            f32x16 sacc[QW];
+            auto scores = [&]() {
+                typename F::v8 kf[NKS];
 #pragma unroll
-            for (int s = 0; s < NKS; ++s)
-                if (!(WI & 8)) kf[s] = *reinterpret_cast<const typename F::v8*>(Sl + sub * 4096 + kofs[s]);
-            f32x16 sacc = negm;
-            if (!(WI & 8)) {
-                sacc = F::mfma(kf[0], qf[0], negm);
+                for (int s = 0; s < NKS; ++s)
+                    if (!(WI & 8)) kf[s] = *reinterpret_cast<const typename F::v8*>(Sl + sub * 4096 + kofs[s]);
+                if (!(WI & 8)) {
 #pragma unroll
-                for (int s = 1; s < NKS; ++s) sacc = F::mfma(kf[s], qf[s], sacc);
-            } else {
+                    for (int w = 0; w < QW; ++w) sacc[w] = F::mfma(kf[0], qf[w][0], negm[w]);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[r] = (float)(r + lane) * 0.01f + m_run;
-            }
+                    for (int s = 1; s < NKS; ++s)
+#pragma unroll
+                        for (int w = 0; w < QW; ++w) sacc[w] = F::mfma(kf[s], qf[w][s], sacc[w]);
+                } else {
+#pragma unroll
+                    for (int w = 0; w < QW; ++w)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) sacc[w][r] = (float)(r + lane) * 0.01f + m_run[w];
+                }
+                if (k0 + sub * 32 + 32 > a.Tk) {   // last, partial sub-tile: keys beyond Tk take no part
+#pragma unroll
+                    for (int w = 0; w < QW; ++w)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                            sacc[w][r] = key < a.Tk ? sacc[w][r] : -INFINITY;
+                        }
+                }
+            };
+            scores();
             // the eight transposed V fragments of this sub-tile, requested now and waited for in front of the second product
             // (inline asm: hipcc puts s_waitcnt vmcnt(0) in front of the ds_read_tr BUILTIN when LDS-DMA is in flight — it
             // cannot tell the stages apart — which would serialise the tile behind the two tiles being fetched)
             v2i vr[DT][2][2];
             if (!(WI & 4)) tr_read8<sub * 32 * 128>(vr, sl_addr + vofs[0], sl_addr + vofs[1]);
-            if (k0 + sub * 32 + 32 > a.Tk) {   // last, partial sub-tile: keys beyond Tk take no part
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = k0 + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    sacc[r] = key < a.Tk ? sacc[r] : -INFINITY;
-                }
-            }
+            // OPTIMISTIC softmax: exponentiate first, look at the maximum only if that went wrong.  p = exp2(s - m) is safe while
+            // s - m stays below the 16-bit range; a lane's sum of its 16 p bounds each of them, so "psum <= 16 * 2^thr" (one compare,
+            // false for inf / NaN too) replaces the 15 v_max + cross-half exchange + compare of the tile maximum on every sub-tile.
+            // When it fails for any query of the wave (and on the first sub-tile, whose m is still 0) the scores are computed again
+            // — K is still in its stage — and the maximum is moved the exact way before they are exponentiated.
+            typename F::v8 pf[QW][2];
             if (!(WI & 1)) {
-                float tmax = fmaxf(fmaxf(sacc[0], sacc[1]), sacc[2]);
+                float psum[QW];
+                bool redo = first;
+                if (!redo) {
+                    bool bad = false;
 #pragma unroll
-                for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[r]), sacc[r + 1]);
-                tmax = fmaxf(tmax, sacc[15]);
-                tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
-                const bool need = first || !(tmax <= a.thr);
-                if (__any(need)) {
-                    const float delta = need ? tmax : 0.f;
-                    const float corr = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+                    for (int w = 0; w < QW; ++w) {
+                        psum[w] = 0.f;
 #pragma unroll
-                    for (int t = 0; t < DT; ++t)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) o[t][r] *= corr;
-                    l_run *= corr;
-                    m_run += delta;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        negm[r] = -m_run;
-                        sacc[r] -= delta;
+                        for (int r = 0; r < 16; ++r) {
+                            sacc[w][r] = __builtin_amdgcn_exp2f(sacc[w][r]);
+                            psum[w] += sacc[w][r];
+                        }
+                        bad |= !(psum[w] <= pbound);
                     }
-                    first = false;
+                    redo = __any(bad);
                 }
-                float psum = 0.f;
+                if (redo) {
+                    if (!first) scores();
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    sacc[r] = __builtin_amdgcn_exp2f(sacc[r]);
-                    psum += sacc[r];
+                    for (int w = 0; w < QW; ++w) {
+                        float tmax = fmaxf(fmaxf(sacc[w][0], sacc[w][1]), sacc[w][2]);
+#pragma unroll
+                        for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, sacc[w][r]), sacc[w][r + 1]);
+                        tmax = fmaxf(tmax, sacc[w][15]);
+                        tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+                        const bool need = first || !(tmax <= a.thr);
+                        if (__any(need)) {
+                            const float delta = need ? tmax : 0.f;          // first tile: may be negative — m becomes the tile's maximum
+                            const float corr = first ? 0.f : __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                            for (int t = 0; t < DT; ++t)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) o[w][t][r] *= corr;
+                            l_run[w] *= corr;
+                            m_run[w] += delta;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                negm[w][r] = -m_run[w];
+                                sacc[w][r] -= delta;
+                            }
+                        }
+                        psum[w] = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            sacc[w][r] = __builtin_amdgcn_exp2f(sacc[w][r]);
+                            psum[w] += sacc[w][r];
+                        }
+                    }
                 }
-                l_run += psum;
+#pragma unroll
+                for (int w = 0; w < QW; ++w) l_run[w] += psum[w];
             }
-            typename F::v8 pf[2];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+            for (int w = 0; w < QW; ++w)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) pf[s2][e] = (T16)sacc[8 * s2 + e];
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pf[w][s2][e] = (T16)sacc[w][8 * s2 + e];
+            first = false;
             if (!(WI & 4)) tr_wait8(vr);
 #pragma unroll
             for (int t = 0; t < DT; ++t) {
                 if (WI & 4) {
-                    o[t][0] += (float)pf[0][0] + (float)pf[1][7];
+#pragma unroll
+                    for (int w = 0; w < QW; ++w) o[w][t][0] += (float)pf[w][0][0] + (float)pf[w][1][7];
                     continue;
                 }
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const typename F::v8 vf = __builtin_bit_cast(typename F::v8, __builtin_shufflevector(vr[t][s2][0], vr[t][s2][1], 0, 1, 2, 3));
-                    o[t] = F::mfma(vf, pf[s2], o[t]);
+#pragma unroll
+                    for (int w = 0; w < QW; ++w) o[w][t] = F::mfma(vf, pf[w][s2], o[w][t]);
                 }
             }
         };
         sub_tile(std::integral_constant<int, 0>{});
         if (k0 + 32 < a.Tk) sub_tile(std::integral_constant<int, 1>{});
     }
-    if (!q_ok) return;
-    const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.f / l_tot;
-    T16* op = reinterpret_cast<T16*>(a.out) + ((int64_t)n * a.Tq + q) * a.ldo + (int64_t)head * a.d;
 #pragma unroll
-    for (int t = 0; t < DT; ++t)
+    for (int w = 0; w < QW; ++w) {
+        if (!q_ok[w]) continue;
+        const float l_tot = l_run[w] + __shfl_xor(l_run[w], 32);
+        const float inv = 1.f / l_tot;
+        T16* op = reinterpret_cast<T16*>(a.out) + ((int64_t)n * a.Tq + q[w]) * a.ldo + (int64_t)head * a.d;
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            const int d = t * 32 + 8 * r4 + 4 * half;
-            typename F::v4 h;
+        for (int t = 0; t < DT; ++t)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h[e] = (T16)(o[t][4 * r4 + e] * inv);
-            *reinterpret_cast<typename F::v4*>(op + d) = h;
-        }
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int d = t * 32 + 8 * r4 + 4 * half;
+                typename F::v4 h;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h[e] = (T16)(o[w][t][4 * r4 + e] * inv);
+                *reinterpret_cast<typename F::v4*>(op + d) = h;
+            }
+    }
 }
 
 // the DMA kernel takes head dim 64 with K / V addressable in 32-bit byte offsets from the (sample, head) base
@@ -553,11 +615,16 @@ template <typename T16>
 void launch_attn16(const A16P& p, int nks, hipStream_t s) {
     const dim3 grid((unsigned)(cdiv(p.Tq, 128) * p.heads * p.N)), block(256);
     if (attn16_dma_ok(p)) {
-        static const bool w8 = getenv("DSD_ATTN16_W8") != nullptr;   // A/B: 8 waves = 256 queries per workgroup
-        if (w8 && p.Tq >= 256)
-            hipLaunchKernelGGL((attention16_dma_kernel<T16, 0, 8>), dim3((unsigned)(cdiv(p.Tq, 256) * p.heads * p.N)), dim3(512), 0, s, p);
-        else
+        // 256 queries per workgroup when the sequence has them (the K / V tile is fetched once for twice the work).  Same-box
+        // A/B inside DiT-B/8 @512 (fp16 / bf16, ms per 12 calls): 8 waves x 32 queries 10.18 / 9.84, 4 waves x 64 queries
+        // 10.29-10.79 / 9.86-9.96, 4 waves x 32 queries 11.09 / 10.43 (and 11.56 / 10.80 before the kernel fitted 128 registers)
+        // (the 4 x 64 instantiation is no longer built: with the optimistic softmax it needs more than 256 registers)
+        static const int variant = getenv("DSD_ATTN16_VARIANT") ? atoi(getenv("DSD_ATTN16_VARIANT")) : 0;   // A/B: 1 = 4 x 32
+        const dim3 grid256((unsigned)(cdiv(p.Tq, 256) * p.heads * p.N));
+        if (p.Tq < 256 || variant == 1)
             hipLaunchKernelGGL((attention16_dma_kernel<T16>), grid, block, 0, s, p);
+        else
+            hipLaunchKernelGGL((attention16_dma_kernel<T16, 0, 8>), grid256, dim3(512), 0, s, p);
         return;
     }
     switch (nks) {
