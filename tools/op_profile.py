@@ -13,6 +13,7 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--ref-batch", type=int, default=16)
 ap.add_argument("--top", type=int, default=40)
 ap.add_argument("--json", default=None)
+ap.add_argument("--dump", default=None, help="write every op of the --batch forward: index, kind, ms, flops, algorithmic bytes")
 args = ap.parse_args()
 cfg = yaml.safe_load(open(os.path.join(ROOT, "configs", "v2-1-cddpm-ds-disc.yaml")))
 torch.manual_seed(2024)
@@ -39,6 +40,10 @@ def ops_at(B):
 
 
 a, r = ops_at(args.batch), ops_at(args.ref_batch)
+if args.dump:
+    with open(args.dump, "w") as f:
+        for i, (k, ms, fl, by) in enumerate(a):
+            f.write(f"{i}\t{k}\t{ms * 1e3:.1f}\t{fl:.4g}\t{by:.4g}\n")
 scale = args.batch / args.ref_batch
 tot_a, tot_r = sum(o[1] for o in a), sum(o[1] for o in r) * scale
 print(f"batch {args.batch}: {tot_a:.2f} ms in {len(a)} ops; batch {args.ref_batch} x {scale:g}: {tot_r:.2f} ms in {len(r)} ops")
