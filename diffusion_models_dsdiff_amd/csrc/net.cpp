@@ -65,7 +65,22 @@ enum { L_CONV, L_RES, L_ATTN, L_DOWN, L_UP };
 struct Layer {
     int kind = 0, cin = 0, cout = 0, ch = 0, heads = 0;
     bool up = false, down = false;
+    int dh = 0;          // L_ATTN as SpatialTransformer (UNetModel(use_spatial_transformer=True)): d_head (> 0), heads = n_heads
 };
+// SpatialTransformer options of a UNetModel handle (openaimodel.py:623-631): trailing integers of its iargs
+struct StOpt {
+    int on = 0, depth = 1, ctx_dim = 0, linear = 0;
+};
+StOpt st_opt_from_iargs(const std::vector<int32_t>& a) {
+    StOpt o;
+    if (a.size() < 12) return o;
+    const int nl = a[10];
+    const size_t base = 12 + 2 * (size_t)nl + (size_t)a[11 + 2 * nl];
+    if (a.size() >= base + 4) {
+        o.on = a[base]; o.depth = a[base + 1]; o.ctx_dim = a[base + 2]; o.linear = a[base + 3];
+    }
+    return o;
+}
 struct Spec {
     std::vector<std::vector<Layer>> input_blocks, output_blocks;
     std::vector<Layer> middle;
@@ -79,7 +94,7 @@ Layer mk_res(int cin, int cout, bool up = false, bool down = false) {
 }
 
 // model.py:282-515
-Spec build_spec(const dsd_config& c, bool plain = false) {
+Spec build_spec(const dsd_config& c, bool plain = false, bool st = false) {
     Spec s;
     const int mc = c.model_channels;
     DSD_CHECK(c.n_levels >= 1 && c.n_levels <= DSD_MAX_LEVELS, "channel_mult must have 1..%d entries", DSD_MAX_LEVELS);
@@ -102,10 +117,16 @@ Spec build_spec(const dsd_config& c, bool plain = false) {
             num_heads = ch / nhc;
             dim_head = nhc;
         }
-        if (c.legacy) dim_head = nhc;
+        if (c.legacy) dim_head = st ? ch / num_heads : nhc;   // (openaimodel.py:745-747)
         const int h_arg = heads_arg < 0 ? num_heads : heads_arg;
         Layer l;
         l.kind = L_ATTN; l.ch = ch;
+        if (st) {   // SpatialTransformer(ch, num_heads, dim_head, ...) — also in the decoder (num_heads, not num_heads_upsample)
+            DSD_CHECK(num_heads > 0 && dim_head > 0, "spatial transformer: heads %d x dim_head %d", num_heads, dim_head);
+            l.heads = num_heads;
+            l.dh = dim_head;
+            return l;
+        }
         if (dim_head == -1) {
             l.heads = h_arg;
         } else {
@@ -209,11 +230,27 @@ void p_attn(dsd_handle* h, const std::string& p, int ch) {
     p_conv1d(h, p + ".qkv", ch, 3 * ch);
     p_conv1d(h, p + ".proj_out", ch, ch);
 }
+void p_btb(dsd_handle* h, const std::string& p, int dim, int heads, int dh, int cd);
+// SpatialTransformer (ldm/modules/attention.py:365-428)
+void p_spatial_transformer(dsd_handle* h, const std::string& p, int in_ch, int heads, int dh, int depth, int ctx_dim, int linear) {
+    const int inner = heads * dh;
+    p_norm(h, p + "norm", in_ch);
+    if (linear) p_lin(h, p + "proj_in", in_ch, inner); else p_conv(h, p + "proj_in", in_ch, inner, 1);
+    for (int d = 0; d < depth; ++d) p_btb(h, p + "transformer_blocks." + std::to_string(d), inner, heads, dh, ctx_dim);
+    if (linear) p_lin(h, p + "proj_out", in_ch, inner); else p_conv(h, p + "proj_out", inner, in_ch, 1);
+}
 void p_layer(dsd_handle* h, const std::string& p, const Layer& L, int ted, bool film) {
     switch (L.kind) {
         case L_CONV: p_conv(h, p, L.cin, L.cout, 3); break;
         case L_RES: p_res(h, p, L.cin, L.cout, ted, film, true); break;
-        case L_ATTN: p_attn(h, p, L.ch); break;
+        case L_ATTN:
+            if (L.dh > 0) {
+                const StOpt o = st_opt_from_iargs(h->iargs);
+                p_spatial_transformer(h, p + ".", L.ch, L.heads, L.dh, o.depth, o.ctx_dim, o.linear);
+            } else {
+                p_attn(h, p, L.ch);
+            }
+            break;
         case L_DOWN: p_conv(h, p + ".op", L.ch, L.ch, 3); break;
         case L_UP: p_conv(h, p + ".conv", L.ch, L.ch, 3); break;
     }
@@ -326,7 +363,9 @@ dsd_config unet_cfg_from_iargs(const std::vector<int32_t>& a) {
     return c;
 }
 void p_plain_unet(dsd_handle* h) {
-    const Spec s = build_spec(h->cfg, true);
+    const StOpt so = st_opt_from_iargs(h->iargs);
+    DSD_CHECK(!so.on || (so.depth == 1 && so.ctx_dim > 0), "UNetModel: spatial transformer needs transformer_depth 1 and a context_dim");
+    const Spec s = build_spec(h->cfg, true, so.on != 0);
     const bool film = h->cfg.use_scale_shift_norm;
     p_lin(h, "time_embed.0", h->cfg.model_channels, s.ted);
     p_lin(h, "time_embed.2", s.ted, s.ted);
@@ -456,15 +495,7 @@ void dsd::net_declare_params(dsd_handle* h) {
             case DSD_BLOCK_CROSSATTN: need(4); p_xattn(h, "", a[0], a[1], a[2], a[3]); break;
             case DSD_BLOCK_FF_GEGLU: need(2); p_ff(h, "", a[0], a[1]); break;
             case DSD_BLOCK_BASIC_TRANSFORMER: need(4); p_btb(h, "", a[0], a[1], a[2], a[3]); break;
-            case DSD_BLOCK_SPATIAL_TRANSFORMER: {
-                need(6);
-                const int inner = a[1] * a[2];
-                p_norm(h, "norm", a[0]);
-                if (a[5]) p_lin(h, "proj_in", a[0], inner); else p_conv(h, "proj_in", a[0], inner, 1);
-                for (int d = 0; d < a[3]; ++d) p_btb(h, "transformer_blocks." + std::to_string(d), inner, a[1], a[2], a[4]);
-                if (a[5]) p_lin(h, "proj_out", a[0], inner); else p_conv(h, "proj_out", inner, a[0], 1);
-                break;
-            }
+            case DSD_BLOCK_SPATIAL_TRANSFORMER: need(6); p_spatial_transformer(h, "", a[0], a[1], a[2], a[3], a[4], a[5]); break;
             case DSD_BLOCK_DIT: p_dit(h, dit_cfg(a)); break;
             case DSD_BLOCK_UNET:
                 h->cfg = unet_cfg_from_iargs(a);
@@ -1208,7 +1239,10 @@ struct Builder {
             switch (L.kind) {
                 case L_CONV: nxt = conv(nm, cur, L.cout, 3, 1, false, nullptr, nullptr, plane, false, true, d, true); break;
                 case L_RES: nxt = res_block(nm, cur, L.cin, L.cout, L.up, L.down, embs.at(emb_i++), d); break;
-                case L_ATTN: nxt = attn_block(nm, cur, L.heads, hd->cfg.use_new_attention_order != 0, d); break;
+                case L_ATTN:
+                    nxt = L.dh > 0 ? spatial_transformer(nm + ".", cur, L.heads, L.dh, 1, &st_ctx, d)
+                                   : attn_block(nm, cur, L.heads, hd->cfg.use_new_attention_order != 0, d);
+                    break;
                 case L_DOWN: nxt = conv(nm + ".op", cur, L.ch, 3, 2, false, nullptr, nullptr, -1, false, true, d, true); break;
                 case L_UP: nxt = conv(nm + ".conv", cur, L.ch, 3, 1, true, nullptr, nullptr, -1, false, true, d, true); break;
             }
@@ -1285,6 +1319,22 @@ struct Builder {
         return y;
     }
     // BasicTransformerBlock._forward (attention.py:326-330); x stays owned by the caller
+    // SpatialTransformer.forward (attention.py:409-428): x + proj_out(blocks(proj_in(GroupNorm(x)))); in NHWC the conv1x1 and
+    // Linear flavours of proj_in / proj_out are the same GEMM.  ctx[d] = context of block d (invalid Tn: self-attention).
+    Tn st_ctx;   // the context every SpatialTransformer of a UNetModel receives (openaimodel.py:946-952)
+    Tn spatial_transformer(const std::string& p, const Tn& x, int heads, int dh, int depth, const Tn* ctx, const Tn* dst = nullptr) {
+        Tn n = gn_act(p + "norm", x, ACT_NONE, 1e-6f);
+        Tn t = conv(p + "proj_in", n, heads * dh, 1);
+        release(n);
+        for (int d = 0; d < depth; ++d) {
+            Tn t2 = btb(p + "transformer_blocks." + std::to_string(d), t, ctx[d].valid() ? &ctx[d] : nullptr, heads);
+            release(t);
+            t = t2;
+        }
+        Tn y = conv(p + "proj_out", t, x.c, 1, 1, false, nullptr, &x, -1, false, true, dst, dst != nullptr);
+        release(t);
+        return y;
+    }
     Tn btb(const std::string& p, const Tn& x, const Tn* ctx, int heads) {
         Tn n1 = lnorm(pre(p, "norm1"), x);
         Tn x1 = xattn(pre(p, "attn1"), n1, nullptr, heads, &x);
@@ -1620,10 +1670,13 @@ void build_unet(Builder& b, int H, int W, bool zero_al_l, bool want_feats, bool 
 
 // --------------------------------------------------------------------------------- UNetModel.forward (openaimodel.py:926-958)
 // x: NCHW [B, in_channels, H, W] (latents, with the `concat` conditioning already appended), aux = timesteps [B] fp32.
-void build_plain_unet(Builder& b, int C, int H, int W, int aux_len) {
+void build_plain_unet(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
     dsd_handle* hd = b.hd;
     const dsd_config& cfg = hd->cfg;
-    const Spec sp = build_spec(cfg, true);
+    const StOpt so = st_opt_from_iargs(hd->iargs);
+    const Spec sp = build_spec(cfg, true, so.on != 0);
+    DSD_CHECK(!so.on || aux_len2 > 0, "UNetModel(use_spatial_transformer=True): context [B, tokens, %d] missing (aux2)", so.ctx_dim);
+    DSD_CHECK(so.on || aux_len2 == 0, "UNetModel without spatial transformer takes no context");
     const int B = b.B;
     const int nds = cfg.n_levels - 1;
     DSD_CHECK(C == cfg.in_channels, "UNetModel: input has %d channels, expected %d", C, cfg.in_channels);
@@ -1674,8 +1727,9 @@ void build_plain_unet(Builder& b, int C, int H, int W, int aux_len) {
             }
         return out;
     };
-    // ---- encoder: h = module(h, emb); hs.append(h)   (:946-948)
+    // ---- encoder: h = module(h, emb, context); hs.append(h)   (:946-948)
     Tn x = b.import_ext(0, B, H, W, C, /*from_nchw=*/true);
+    if (so.on) b.st_ctx = b.import_ext(2, B, aux_len2, 1, so.ctx_dim, false);
     std::vector<Tn> hs;
     Tn cur = x;
     for (size_t bi = 0; bi < sp.input_blocks.size(); ++bi) {
@@ -1739,6 +1793,7 @@ void build_plain_unet(Builder& b, int C, int H, int W, int aux_len) {
     b.release(a);
     b.export_out(y, /*to_nchw=*/true);
     b.release(y);
+    if (so.on) b.release(b.st_ctx);
     b.release(emb_all);
 }
 
@@ -1936,7 +1991,7 @@ void build_block(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
         return;
     }
     if (kind == DSD_BLOCK_UNET) {
-        build_plain_unet(b, C, H, W, aux_len);
+        build_plain_unet(b, C, H, W, aux_len, aux_len2);
         return;
     }
     Tn x = b.import_ext(0, B, H, W, C, !token);
@@ -1980,22 +2035,12 @@ void build_block(Builder& b, int C, int H, int W, int aux_len, int aux_len2) {
             break;
         }
         case DSD_BLOCK_SPATIAL_TRANSFORMER: {
-            // attention.py:411-428; in NHWC the conv1x1 and Linear flavours of proj_in/proj_out are the same GEMM
-            const int inner = a[1] * a[2], depth = a[3];
+            const int depth = a[3];
             DSD_CHECK(depth >= 1 && depth <= 2, "spatial transformer block handle supports depth 1..2 (two context inputs)");
             Tn ctx[2];
             if (aux_len > 0) ctx[0] = b.import_ext(1, B, aux_len, 1, a[4], false);
             if (depth > 1 && aux_len2 > 0) ctx[1] = b.import_ext(2, B, aux_len2, 1, a[4], false);
-            Tn n = b.gn_act("norm", x, ACT_NONE, 1e-6f);
-            Tn t = b.conv("proj_in", n, inner, 1);
-            b.release(n);
-            for (int d = 0; d < depth; ++d) {
-                Tn t2 = b.btb("transformer_blocks." + std::to_string(d), t, ctx[d].valid() ? &ctx[d] : nullptr, a[1]);
-                b.release(t);
-                t = t2;
-            }
-            y = b.conv("proj_out", t, a[0], 1, 1, false, nullptr, &x);
-            b.release(t);
+            y = b.spatial_transformer("", x, a[1], a[2], depth, ctx);
             for (auto& c : ctx) b.release(c);
             break;
         }

@@ -1,6 +1,6 @@
 """UNetModel — drop-in for ldm/modules/diffusionmodules/openaimodel.py:571-958, the plain single-stream denoiser that the
 latent path runs on the VAE latents (configs/v2-1-stable-unclip-h-inference.yaml:33-50: no spatial transformer, no class
-embedding).  Same constructor keywords, ``state_dict`` names and ``forward(x, timesteps, context=None, y=None)``; the
+embedding); ``use_spatial_transformer=True`` (cross-attention on ``context``, transformer_depth 1) is built as well.  Same constructor keywords, ``state_dict`` names and ``forward(x, timesteps, context=None, y=None)``; the
 arithmetic runs in libdsdiff.so (DSD_BLOCK_UNET, include/dsdiff.h) on the same kernels as the four-stream DSUnetModel.
 The reference's building blocks are re-exported under their original names.
 """
@@ -26,8 +26,14 @@ class UNetModel(_Block):
         super().__init__()
         if use_spatial_transformer:
             assert context_dim is not None, 'use_spatial_transformer=True needs context_dim (the width of the cross-attention conditioning)'
-            raise NotImplementedError("the latent path's yaml sets use_spatial_transformer: False; the transformer blocks exist as "
-                                      "block handles (blocks.SpatialTransformer) but not inside this model")
+            if isinstance(context_dim, (list, tuple)):      # (a ListConfig in the reference: one entry per transformer block)
+                context_dim = list(context_dim)
+                assert len(set(context_dim)) == 1, "one context width for all transformer blocks"
+                context_dim = context_dim[0]
+            if transformer_depth != 1:
+                # the reference builds SpatialTransformer(..., depth, context_dim=<int>) and indexes context_dim[d] / context[d]:
+                # with one conditioning tensor (openaimodel.py:946-952) only depth 1 runs there either
+                raise NotImplementedError("UNetModel(use_spatial_transformer=True) takes transformer_depth=1 (one context tensor)")
         if context_dim is not None:
             assert use_spatial_transformer, 'context_dim is only meaningful with use_spatial_transformer=True'
         if num_heads == -1:
@@ -50,9 +56,11 @@ class UNetModel(_Block):
         self.num_classes = None
         self.dtype = torch.float32
         ar = self.attention_resolutions
+        self.use_spatial_transformer, self.context_dim = bool(use_spatial_transformer), context_dim
+        st = [1, int(transformer_depth), int(context_dim), int(bool(use_linear_in_transformer))] if use_spatial_transformer else []
         self._create(_lib.BLOCK_UNET, [in_channels, model_channels, out_channels, num_heads, num_head_channels, num_heads_upsample,
                                        int(bool(use_scale_shift_norm)), int(bool(resblock_updown)), int(bool(use_new_attention_order)),
-                                       int(bool(legacy)), len(channel_mult)] + channel_mult + nrb + [len(ar)] + ar, device_index)
+                                       int(bool(legacy)), len(channel_mult)] + channel_mult + nrb + [len(ar)] + ar + st, device_index)
         half = model_channels // 2
         freqs = torch.exp(-math.log(10000) * torch.arange(start=0, end=half, dtype=torch.float32) / half).contiguous()
         check(lib().dsd_set_timestep_freqs(self._h, C.c_void_p(freqs.data_ptr()), half))
@@ -73,7 +81,15 @@ class UNetModel(_Block):
         t = timesteps.to(x.device).float().contiguous()
         assert t.shape == (B,)
         out = torch.empty(self._out_shape(x), device=x.device, dtype=torch.float32)
-        check(lib().dsd_block_forward(self._h, dptr(x), B, Cc, H, W, dptr(t), 1, None, 0, dptr(out), stream_ptr()))
+        if self.use_spatial_transformer:
+            if context is None:
+                raise ValueError("UNetModel(use_spatial_transformer=True): context [B, tokens, context_dim] is required")
+            ctx = context.to(x.device).float().contiguous()
+            assert ctx.dim() == 3 and ctx.shape[0] == B and ctx.shape[2] == self.context_dim, tuple(ctx.shape)
+            check(lib().dsd_block_forward(self._h, dptr(x), B, Cc, H, W, dptr(t), 1, dptr(ctx), ctx.shape[1], dptr(out), stream_ptr()))
+        else:
+            assert context is None, "context is only consumed by the spatial-transformer variant"
+            check(lib().dsd_block_forward(self._h, dptr(x), B, Cc, H, W, dptr(t), 1, None, 0, dptr(out), stream_ptr()))
         return out
 
     def convert_to_fp16(self):

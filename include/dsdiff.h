@@ -270,8 +270,9 @@ enum { DSD_BLOCK_RES = 0, DSD_BLOCK_ATTN = 1, DSD_BLOCK_UPSAMPLE = 2, DSD_BLOCK_
        /* transformer backbone (SURVEY f-4): DiT of UNet_DS_Diff/DiT_models.py:145-262 (adaLN-Zero blocks, timm-style
         * PatchEmbed / Attention / Mlp); parameter names are the DiT state_dict's */
        DSD_BLOCK_DIT = 12,
-       /* the plain single-stream UNetModel of ldm/modules/diffusionmodules/openaimodel.py:571-958 (no spatial transformer,
-        * no class embedding): the denoiser that consumes the VAE latents in the latent path */
+       /* the plain single-stream UNetModel of ldm/modules/diffusionmodules/openaimodel.py:571-958 (no class embedding): the
+        * denoiser that consumes the VAE latents in the latent path; optionally with a SpatialTransformer on `context` in
+        * every attention slot (use_spatial_transformer=True, :761-765,818-822,872-876) */
        DSD_BLOCK_UNET = 13 };
 /* iargs by kind:
  *   RES: cin, cout, emb_ch, use_scale_shift_norm, up, down      ATTN: ch, heads, new_order
@@ -289,8 +290,10 @@ enum { DSD_BLOCK_RES = 0, DSD_BLOCK_ATTN = 1, DSD_BLOCK_UPSAMPLE = 2, DSD_BLOCK_
  *        (128 entries) installs the caller's frequency table as for the U-Net.
  *   UNET: in_channels, model_channels, out_channels, num_heads, num_head_channels, num_heads_upsample, use_scale_shift_norm,
  *        resblock_updown, use_new_attention_order, legacy, len(channel_mult), channel_mult..., num_res_blocks per level...,
- *        len(attention_resolutions), attention_resolutions...  (the ctor kwargs of openaimodel.py:601-633).
- *        x [B,in_channels,H,W], aux = timesteps [B] fp32 (aux_len 1); out [B,out_channels,H,W]. */
+ *        len(attention_resolutions), attention_resolutions...  (the ctor kwargs of openaimodel.py:601-633), optionally followed by
+ *        use_spatial_transformer, transformer_depth (1), context_dim, use_linear_in_transformer.
+ *        x [B,in_channels,H,W], aux = timesteps [B] fp32 (aux_len 1), aux2 = context [B,tokens,context_dim] with
+ *        aux_len2 = tokens (spatial-transformer variant only, else NULL / 0); out [B,out_channels,H,W]. */
 int dsd_block_create(int kind, const int32_t* iargs, int n_iargs, int device, dsd_handle** out);
 /* x: NCHW [B,C,H,W] (token blocks: [B,N,C] passed as H=N, W=1 "NHWC"), aux: emb [B,emb_ch] for RES,
  * context [B,Nc,Cc] for cross-attention kinds (aux2/aux_len2 = second context for depth-2 spatial

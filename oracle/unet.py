@@ -37,6 +37,11 @@ class UNetConfig:
     use_new_attention_order: bool = False
     legacy: bool = True
     conv_resample: bool = True
+    # UNetModel(use_spatial_transformer=True) only (ldm/modules/diffusionmodules/openaimodel.py:623-631,761-765)
+    use_spatial_transformer: bool = False
+    transformer_depth: int = 1
+    context_dim: object = None
+    use_linear_in_transformer: bool = False
     # ignored by the graph: image_size, dropout(=0), use_checkpoint, adm_in_channels, ...
 
     @staticmethod
@@ -71,7 +76,9 @@ def build_spec(cfg: UNetConfig) -> dict:
             num_heads = ch // nhc
             dim_head = nhc
         if cfg.legacy:
-            dim_head = nhc
+            dim_head = ch // num_heads if cfg.use_spatial_transformer else nhc   # openaimodel.py:745-747
+        if cfg.use_spatial_transformer:      # SpatialTransformer(ch, num_heads, dim_head, ...) — num_heads in the decoder too
+            return {"kind": "st", "ch": ch, "heads": num_heads, "dim_head": dim_head}
         h_arg = num_heads if heads_arg is None else heads_arg
         heads = h_arg if dim_head == -1 else ch // dim_head
         return {"kind": "attn", "ch": ch, "heads": heads}
@@ -277,7 +284,7 @@ class _Net:
         a = F.conv1d(a, self.p(prefix + ".proj_out.weight"), self.p(prefix + ".proj_out.bias"))
         return (xf + a).reshape(b, c, hh, ww)
 
-    def block(self, prefix, layers, x, emb):
+    def block(self, prefix, layers, x, emb, context=None):
         """TimestepEmbedSequential.forward openaimodel.py:80-90."""
         for li, L in enumerate(layers):
             nm = f"{prefix}.{li}"
@@ -288,6 +295,10 @@ class _Net:
                 x = self.res(nm, L, x, emb)
             elif k == "attn":
                 x = self.attn(nm, L, x)
+            elif k == "st":
+                from .xattn import spatial_transformer
+                x = spatial_transformer(self.sd, nm, x, [context] * self.cfg.transformer_depth, L["heads"], self.cfg.transformer_depth,
+                                        self.cfg.use_linear_in_transformer)
             elif k == "down":
                 x = self.conv(nm + ".op", x, stride=2)            # Downsample openaimodel.py:162-164
             elif k == "up":
@@ -358,21 +369,21 @@ def unet_forward(cfg: UNetConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, 
 
 
 @torch.no_grad()
-def plain_unet_forward(cfg: UNetConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, timesteps: torch.Tensor):
+def plain_unet_forward(cfg: UNetConfig, sd: Dict[str, torch.Tensor], x: torch.Tensor, timesteps: torch.Tensor, context=None):
     """UNetModel.forward (ldm/modules/diffusionmodules/openaimodel.py:926-958): the single-stream denoiser of the latent
-    path (no class embedding, no spatial transformer)."""
+    path (no class embedding); with cfg.use_spatial_transformer every attention slot is a SpatialTransformer on `context`."""
     net = _Net(cfg, sd)
     t_emb = timestep_embedding(timesteps, cfg.model_channels)
     emb = F.linear(t_emb, net.p("time_embed.0.weight"), net.p("time_embed.0.bias"))
     emb = F.linear(F.silu(emb), net.p("time_embed.2.weight"), net.p("time_embed.2.bias"))
     h, hs = x.float(), []
     for bi, layers in enumerate(net.spec["input_blocks"]):
-        h = net.block(f"input_blocks.{bi}", layers, h, emb)
+        h = net.block(f"input_blocks.{bi}", layers, h, emb, context)
         hs.append(h)
-    h = net.block("middle_block", net.spec["middle"], h, emb)
+    h = net.block("middle_block", net.spec["middle"], h, emb, context)
     for bi, layers in enumerate(net.spec["output_blocks"]):
         h = torch.cat([h, hs.pop()], dim=1)
-        h = net.block(f"output_blocks.{bi}", layers, h, emb)
+        h = net.block(f"output_blocks.{bi}", layers, h, emb, context)
     return net.conv("out.2", F.silu(net.gn("out.0", h)))
 
 
