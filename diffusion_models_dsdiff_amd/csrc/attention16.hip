@@ -320,8 +320,12 @@ static __device__ __forceinline__ i32x4 make_rsrc16(const void* base, unsigned b
 }
 
 typedef int v2i __attribute__((ext_vector_type(2)));
-// eight ds_read_b64_tr_b16 (d tile t = 0, 1 x k-step s2 = 0, 1 x key octet j = 0, 1) at a0 / a1 + OFF + (16 s2 + 8 j) * 128; the
-// results are NOT counted by hipcc: tr_wait8 in front of the first use
+// eight ds_read_b64_tr_b16 (d tile t = 0, 1 x k-step s2 = 0, 1 x key octet j = 0, 1) at a0 / a1 + OFF + (16 s2 + 8 j) * 128 AND the
+// wait for them, in ONE statement.  (The first version issued the reads in front of the softmax and waited in a second statement
+// in front of the second product, to hide their latency behind the softmax of the same wave.  hipcc does not know that the
+// destination registers of an asm load are in flight: under the 128-register cap of the 8-wave build it spilled four of them
+// between the two statements and reused them for v_exp results — non-finite output, caught by tests/test_half_gpu.py.  One
+// statement leaves no live range to tamper with; the latency is covered by the other three waves of the SIMD.)
 template <int OFF>
 static __device__ __forceinline__ void tr_read8(v2i (&r)[2][2][2], unsigned a0, unsigned a1) {
     asm volatile(
@@ -332,18 +336,12 @@ static __device__ __forceinline__ void tr_read8(v2i (&r)[2][2][2], unsigned a0, 
         "ds_read_b64_tr_b16 %4, %9 offset:%10\n\t"
         "ds_read_b64_tr_b16 %5, %9 offset:%11\n\t"
         "ds_read_b64_tr_b16 %6, %9 offset:%12\n\t"
-        "ds_read_b64_tr_b16 %7, %9 offset:%13"
+        "ds_read_b64_tr_b16 %7, %9 offset:%13\n\t"
+        "s_waitcnt lgkmcnt(0)"
         : "=&v"(r[0][0][0]), "=&v"(r[0][0][1]), "=&v"(r[0][1][0]), "=&v"(r[0][1][1]), "=&v"(r[1][0][0]), "=&v"(r[1][0][1]),
           "=&v"(r[1][1][0]), "=&v"(r[1][1][1])
         : "v"(a0), "v"(a1), "i"(OFF), "i"(OFF + 8 * 128), "i"(OFF + 16 * 128), "i"(OFF + 24 * 128)
         : "memory");
-}
-static __device__ __forceinline__ void tr_wait8(v2i (&r)[2][2][2]) {
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(r[0][0][0]), "+v"(r[0][0][1]), "+v"(r[0][1][0]), "+v"(r[0][1][1]), "+v"(r[1][0][0]), "+v"(r[1][0][1]),
-                   "+v"(r[1][1][0]), "+v"(r[1][1][1])
-                 :
-                 : "memory");
 }
 
 // NW waves (4 or 8) share the stages, each wave owns QW blocks of 32 queries (1 or 2).  8 waves = 256 queries per workgroup halve
@@ -496,11 +494,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attention16_dma_kern
                 }
             };
             scores();
-            // the eight transposed V fragments of this sub-tile, requested now and waited for in front of the second product
-            // (inline asm: hipcc puts s_waitcnt vmcnt(0) in front of the ds_read_tr BUILTIN when LDS-DMA is in flight — it
-            // cannot tell the stages apart — which would serialise the tile behind the two tiles being fetched)
-            v2i vr[DT][2][2];
-            if (!(WI & 4)) tr_read8<sub * 32 * 128>(vr, sl_addr + vofs[0], sl_addr + vofs[1]);
             // OPTIMISTIC softmax: exponentiate first, look at the maximum only if that went wrong.  p = exp2(s - m) is safe while
             // s - m stays below the 16-bit range; a lane's sum of its 16 p bounds each of them, so "psum <= 16 * 2^thr" (one compare,
             // false for inf / NaN too) replaces the 15 v_max + cross-half exchange + compare of the tile maximum on every sub-tile.
@@ -567,20 +560,27 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void attention16_dma_kern
 #pragma unroll
                     for (int e = 0; e < 8; ++e) pf[w][s2][e] = (T16)sacc[w][8 * s2 + e];
             first = false;
-            if (!(WI & 4)) tr_wait8(vr);
+            // the eight transposed V fragments of this sub-tile (inline asm: hipcc puts s_waitcnt vmcnt(0) in front of the
+            // ds_read_tr BUILTIN when LDS-DMA is in flight — it cannot tell the stages apart — which would serialise the tile
+            // behind the two tiles being fetched)
+            v2i vr[DT][2][2];
+            if (!(WI & 4)) tr_read8<sub * 32 * 128>(vr, sl_addr + vofs[0], sl_addr + vofs[1]);
+            if (WI & 4) {
 #pragma unroll
-            for (int t = 0; t < DT; ++t) {
-                if (WI & 4) {
+                for (int t = 0; t < DT; ++t)
 #pragma unroll
                     for (int w = 0; w < QW; ++w) o[w][t][0] += (float)pf[w][0][0] + (float)pf[w][1][7];
-                    continue;
-                }
+            } else {
+                // k-step outside, d tile inside: consecutive MFMAs go to DIFFERENT accumulators (a dependent pair would wait
+                // for the first one's result)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const typename F::v8 vf = __builtin_bit_cast(typename F::v8, __builtin_shufflevector(vr[t][s2][0], vr[t][s2][1], 0, 1, 2, 3));
+                for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int w = 0; w < QW; ++w) o[w][t] = F::mfma(vf, pf[w][s2], o[w][t]);
-                }
+                    for (int t = 0; t < DT; ++t) {
+                        const typename F::v8 vf = __builtin_bit_cast(typename F::v8, __builtin_shufflevector(vr[t][s2][0], vr[t][s2][1], 0, 1, 2, 3));
+#pragma unroll
+                        for (int w = 0; w < QW; ++w) o[w][t] = F::mfma(vf, pf[w][s2], o[w][t]);
+                    }
             }
         };
         sub_tile(std::integral_constant<int, 0>{});

@@ -139,3 +139,32 @@ def test_plain_unet_parameter_table_matches_reference_names():
             got[name.value.decode()] = tuple(shape[k] for k in range(ndim.value))
         L.dsd_destroy(h)
         assert got == {n: tuple(s) for n, s in json.loads(str(g[key + "_params"]))}
+
+
+def test_no_product_kernel_spills_or_uses_scratch():
+    """Every gfx950 kernel embedded in the shipped library is read back (AMDGPU metadata note of each code object,
+    tools/kernel_resources.py): no kernel on a product path may spill registers or use scratch memory.  Besides the cost, two
+    kernels keep registers that an inline-asm load is still filling live across compiler-scheduled code: a spill
+    of such a register is silent corruption (seen once, round 3: attention16_dma_kernel under its 128-register cap).
+    Exempt: the diagnostic what-if instantiations of the half-precision GEMM that keep every fragment in registers on purpose
+    (timing only, never on a product path) and the scalar-register spills of the opt-in Winograd kernel."""
+    import re
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    ks = kernel_resources.kernels()
+    assert len(ks) > 150                                   # the parser sees the library's kernels at all
+    names = " ".join(k["name"] for k in ks)
+    for must in ("conv_split_ad_kernel", "attention16_dma_kernel", "gemm16_kernel", "conv_out1_kernel", "sampler_update_kernel"):
+        assert must in names, must
+    bad = []
+    for k in ks:
+        diag_gemm = re.search(r"gemm16_kernelIDF16_Li0ELi(2|3|7|15)E", k["name"]) is not None
+        if diag_gemm:
+            continue
+        if k["scratch"] or k["vgpr_spills"] or (k["sgpr_spills"] and "conv_wino_kernel" not in k["name"]):
+            bad.append(k)
+    assert not bad, bad
+    # the 8-wave attention kernel must fit two workgroups per CU
+    a8 = [k for k in ks if "attention16_dma_kernel" in k["name"] and "Li0ELi8ELi1E" in k["name"]]
+    assert a8 and all(k["vgpr"] <= 128 for k in a8), a8
