@@ -22,6 +22,8 @@
 //   EPI_STORE   y16 = round16(acc + bias)             columns < qcols first multiplied by qscale (the attention's q scale)
 //   EPI_GELU    y16 = round16(gelu_tanh(round16(acc + bias)))                                   (Mlp: fc1 -> GELU)
 //   EPI_GATED   x32[m][n] += gate[m / T][n] * round16(acc + bias)                               (x + gate * f(...), fp32 stream)
+#include <cstdlib>
+
 #include "kernels.h"
 
 namespace dsd {
@@ -29,6 +31,7 @@ namespace dsd {
 namespace g16 {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -47,12 +50,14 @@ struct Frag<_Float16> {
     using v8 = f16x8;
     using v4 = f16x4;
     static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
 };
 template <>
 struct Frag<__bf16> {
     using v8 = bf16x8;
     using v4 = bf16x4;
     static __device__ __forceinline__ f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+    static __device__ __forceinline__ f32x16 mfma32(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
 };
 
 // F.gelu(approximate="tanh") = 0.5 v (1 + tanh(u)), u = sqrt(2/pi) (v + 0.044715 v^3); 0.5 (1 + tanh u) = 1 / (1 + exp(-2u)):
@@ -83,7 +88,10 @@ struct G16P {
 // WI: what-if bits of the diagnostic instantiations (dsd_bench_gemm_half; results are then garbage): 1 no LDS-DMA staging in the
 // loop, 2 fragments read from LDS once (not per k-tile), 4 no epilogue, 8 no barrier, 32 the DMA is issued but never waited for (barrier only),
 // 16 the output of every m tile stored over tile 0's rows (stays in L2)
-template <typename T16, int EPI, int WI = 0>
+// M32: the same tile on v_mfma_f32_32x32x16 (a wave's 128 n x 64 m = 4 x 2 accumulator tiles of 32 x 32, four k-steps of 16 per
+// k-tile).  Same matrix-pipe cycles; an MFMA of this shape holds the wave's issue port for 8 of its 32 cycles instead of 8 of 16,
+// which leaves the DMA / ds_read / address instructions of the two waves of a SIMD twice the issue slots.
+template <typename T16, int EPI, int WI = 0, bool M32 = false>
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
     using F = Frag<T16>;
     // [stage][W tile | X tile]; after the k-loop the same memory transposes the output tile (8 waves x 64 rows x 272 B)
@@ -143,6 +151,124 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
     const int foff0 = frow * 128 + (((lane >> 4) ^ ((frow >> 1) & 7)) << 4);   // ks = 0; ks = 1: ^ 64
     const int aoff = wn * (128 * 128) + foff0;                                 // W tile: rows wn * 128 + 16 i
     const int boff = G_TILE_BYTES + wm * (64 * 128) + foff0;                   // X tile: rows wm * 64 + 16 j
+
+    if constexpr (M32) {
+        // ---- the 32x32x16 build: fragment = row (lane & 31) of a 32-row tile, 16-byte chunk 2 ks + (lane >> 5), ks = 0..3; the
+        // same XOR ((row >> 1) & 7): 16 consecutive lanes = 16 consecutive rows of one chunk = 16 different slots of the bank row
+        const int frow32 = lane & 31, half = lane >> 5;
+        const int fsw = (frow32 >> 1) & 7;
+        const int abase = wn * (128 * 128) + frow32 * 128;                  // + i * 4096 (32 rows)
+        const int bbase = G_TILE_BYTES + wm * (64 * 128) + frow32 * 128;    // + j * 4096
+        f32x16 c32[4][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c32[i][j][r] = 0.f;
+        const int nkt32 = (p.K + GBK - 1) / GBK;
+        stage(0, 0);
+        __syncthreads();
+        typename F::v8 a32[2][4], b32[2][2];
+        auto read32 = [&](const unsigned char* sb, int ks, typename F::v8 (&a)[4], typename F::v8 (&b)[2]) {
+            const int ch = ((2 * ks + half) ^ fsw) << 4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) b[j] = *reinterpret_cast<const typename F::v8*>(sb + bbase + j * 4096 + ch);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const typename F::v8*>(sb + abase + i * 4096 + ch);
+        };
+        for (int t = 0; t < nkt32; ++t) {
+            const int buf = t & 1;
+            const unsigned char* sb = lds + buf * (2 * G_TILE_BYTES);
+            read32(sb, 0, a32[0], b32[0]);
+            if (t + 1 < nkt32) stage(buf ^ 1, (t + 1) * GBK);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) read32(sb, ks + 1, a32[(ks + 1) & 1], b32[(ks + 1) & 1]);   // the next k-step's fragments are on their way
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) c32[i][j] = F::mfma32(a32[ks & 1][i], b32[ks & 1][j], c32[i][j]);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            __syncthreads();
+        }
+        // ---- epilogue.  c32[i][j][r]: n = bn0 + wn*128 + 32 i + 8 (r >> 2) + 4 (lane >> 5) + (r & 3), m = bm0 + wm*64 + 32 j + (lane & 31):
+        // again four consecutive n of one row per register quad
+        const int nl32 = bn0 + wn * 128 + half * 4;     // + 32 i + 8 g
+        const int ml32 = bm0 + wm * 64 + frow32;        // + 32 j
+        const int rows_left32 = min(p.M - bm0, GBM);
+        if (EPI == 2) {
+            float* xb = p.x32 + (int64_t)bm0 * p.ldx32;
+            const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (unsigned)rows_left32 * (unsigned)p.ldx32 * 4u, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = ml32 + j * 32;
+                const int mc = min(m, p.M - 1);
+                const float* gp = p.gate + (int64_t)(mc / p.T) * p.gate_stride;
+                const unsigned rowoff = (unsigned)(m - bm0) * (unsigned)p.ldx32 * 4u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    f32x4 xv[4], gv[4], bq[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = nl32 + i * 32 + g * 8;
+                        const unsigned off = (m < p.M && n < p.N) ? rowoff + (unsigned)n * 4u : 0xFFFFFFF0u;
+                        xv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+                        gv[g] = *reinterpret_cast<const f32x4*>(gp + min(n, p.N - 4));
+                        bq[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + min(n, p.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = nl32 + i * 32 + g * 8;
+                        const unsigned off = (m < p.M && n < p.N) ? rowoff + (unsigned)n * 4u : 0xFFFFFFF0u;
+                        f32x4 r;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) r[e] = fmaf(gv[g][e], (float)(T16)(c32[i][j][4 * g + e] + bq[g][e]), xv[g][e]);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, r), rx, off, 0, 0);
+                    }
+                }
+            }
+        } else {
+            unsigned char* wb = lds + wave * (64 * G_EROW);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = nl32 + i * 32 + g * 8;
+                    const f32x4 bq = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + min(n, p.N - 4)) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = c32[i][j][4 * g + e] + bq[e];
+                        if (EPI == 0 && n < p.qcols) v *= p.qscale;
+                        typename F::v4 h;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (T16)v[e];
+                        if (EPI == 1) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) h[e] = (T16)gelu_tanh_f((float)h[e]);
+                        }
+                        *reinterpret_cast<typename F::v4*>(wb + (j * 32 + frow32) * G_EROW + (i * 32 + g * 8 + half * 4) * 2) = h;
+                    }
+                }
+            }
+            T16* yb = reinterpret_cast<T16*>(p.y16) + (int64_t)bm0 * p.ldy;
+            const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)yb, 0, (unsigned)rows_left32 * (unsigned)p.ldy * 2u, 0x00020000);
+            const int nc = bn0 + wn * 128 + (lane & 15) * 8;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int row = it * 4 + (lane >> 4);
+                const int m = bm0 + wm * 64 + row;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(wb + row * G_EROW + (lane & 15) * 16);
+                const unsigned off = (m < p.M && nc < p.N) ? (unsigned)(m - bm0) * (unsigned)p.ldy * 2u + (unsigned)nc * 2u : 0xFFFFFFF0u;
+                __builtin_amdgcn_raw_buffer_store_b128(v, ry, off, 0, 0);
+            }
+        }
+        return;
+    }
 
     f32x4 acc[8][4];
 #pragma unroll
@@ -334,7 +460,11 @@ __global__ __launch_bounds__(256) void ln_modulate16_kernel(const float* __restr
 
 template <typename T16, int EPI>
 void launch_gemm16(const G16P& p, hipStream_t s) {
-    hipLaunchKernelGGL((gemm16_kernel<T16, EPI>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, s, p);
+    static const bool m32 = getenv("DSD_GEMM16_M32") != nullptr;   // A/B: the 32x32x16 build
+    if (m32)
+        hipLaunchKernelGGL((gemm16_kernel<T16, EPI, 0, true>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, s, p);
+    else
+        hipLaunchKernelGGL((gemm16_kernel<T16, EPI>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, s, p);
 }
 void launch_gemm16_whatif(const G16P& p, int wi, hipStream_t s) {
     const dim3 g((unsigned)(p.tiles_m * p.tiles_n)), b(512);
@@ -348,6 +478,7 @@ void launch_gemm16_whatif(const G16P& p, int wi, hipStream_t s) {
         case 15: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 15>), g, b, 0, s, p); break;
         case 16: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 16>), g, b, 0, s, p); break;
         case 32: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 32>), g, b, 0, s, p); break;
+        case 64: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 0, true>), g, b, 0, s, p); break;   // the 32x32x16 build
         default: fail("gemm16 what-if %d is not instantiated (0, 1, 2, 3, 4, 7, 15, 16, 32)", wi);
     }
 }
