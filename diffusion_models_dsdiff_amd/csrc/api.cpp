@@ -262,8 +262,9 @@ int dsd_set_stream_lanes(dsd_handle* h, int on, int max_pixels) {
     DSD_TRY
     DSD_CHECK(h, "null handle");
     const int px = max_pixels > 0 ? max_pixels : h->lane_pixels;
-    if (h->use_lanes != (on != 0) || h->lane_pixels != px) {
-        h->use_lanes = on != 0;
+    const int mode = on == 2 ? 2 : (on != 0);   // 2: the plan of the lanes (tile choices included), launched on ONE stream (tests)
+    if (h->use_lanes != mode || h->lane_pixels != px) {
+        h->use_lanes = mode;
         h->lane_pixels = px;
         h->plan.valid = false;   // the emission order of the plan (and what the arena may recycle) depends on it
         net_drop_graph(h);

@@ -615,7 +615,7 @@ static int conv_variant(const ConvArgs& a) {
 // t_fix = per-tile staging/barrier cycles that do not shrink with NT, t_mfma = matrix-pipe cycles per 32 columns per
 // tile (fp32: 16 x 64, bf16x6: 12 x 32, bf16x3: 6 x 32).  Big layers get NT = 5 (weights and A staging amortised over the
 // widest tile); small-M layers get narrower tiles so the grid still fills the chip.
-static int pick_nt(int Cout, int tiles_m, int precision) {
+static int pick_nt(int Cout, int tiles_m, int precision, int lanes = 1) {
     static const int force = [] {
         const char* e = getenv("DSD_FORCE_NT");   // experiments only
         return e ? atoi(e) : 0;
@@ -627,7 +627,7 @@ static int pick_nt(int Cout, int tiles_m, int precision) {
     int best = 1;
     double best_t = 1e300;
     for (int nt = 5; nt >= 1; --nt) {
-        const int64_t blocks = (int64_t)tiles_m * cdiv(t32, nt);
+        const int64_t blocks = (int64_t)tiles_m * cdiv(t32, nt) * std::max(1, lanes);   // (what shares the chip with this launch)
         const double t = (double)cdiv(blocks, 512) * (t_fix + nt * t_mf);
         if (t < best_t * 0.999) {
             best_t = t;
@@ -655,7 +655,7 @@ size_t conv2d_scratch_bytes(const ConvArgs& a) {
     const int tm = cdiv(M, BM);
     if (effective_precision(a, tm) == PREC_F32) return 0;
     int nt, ks;
-    conv2d_split_plan(a, pick_nt(a.Cout, tm, a.precision), &nt, &ks);
+    conv2d_split_plan(a, pick_nt(a.Cout, tm, a.precision, a.lanes), &nt, &ks);
     return ks > 1 ? (size_t)ks * M * a.Cout * sizeof(float) : 0;
 }
 
@@ -689,7 +689,7 @@ int conv2d_stats_chunks(const ConvArgs& a) {
     const int tm = cdiv(M, BM);
     const int pr = effective_precision(a, tm);
     if (pr == PREC_F32) return 0;
-    int nt = pick_nt(a.Cout, tm, pr), ks = 1, ad = 0;
+    int nt = pick_nt(a.Cout, tm, pr, a.lanes), ks = 1, ad = 0;
     conv2d_split_plan(a, nt, &nt, &ks, &ad);
     if (ks > 1 || (ad == 1 && nt >= 4)) return 0;   // (128-row kernels with >= 4 column tiles have no registers for it)
     const int rows = ad == 2 ? 2 * BM : BM;
@@ -705,7 +705,7 @@ bool conv2d_fuses_gn(const ConvArgs& a) {
     conv_out_hw(a, &OH, &OW);
     const int tm = cdiv((int64_t)a.N * OH * OW, BM);
     if (effective_precision(a, tm) != PREC_BF16X6) return false;
-    int nt = pick_nt(a.Cout, tm, PREC_BF16X6), ks = 1, ad = 0;
+    int nt = pick_nt(a.Cout, tm, PREC_BF16X6, a.lanes), ks = 1, ad = 0;
     conv2d_split_plan(a, nt, &nt, &ks, &ad, true);
     return conv2d_split_tr(a, nt, ks, ad);
 }
@@ -715,7 +715,7 @@ void conv2d_plan_query(const ConvArgs& a, int* structure, int* nt_out, int* ks_o
     conv_out_hw(a, &OH, &OW);
     const int tm = cdiv((int64_t)a.N * OH * OW, BM);
     const int pr = effective_precision(a, tm);
-    int nt = pick_nt(a.Cout, tm, pr), ks = 1, ad = -1;
+    int nt = pick_nt(a.Cout, tm, pr, a.lanes), ks = 1, ad = -1;
     if (pr != PREC_F32) conv2d_split_plan(a, nt, &nt, &ks, &ad);
     *structure = ad;
     *nt_out = nt;
@@ -736,7 +736,7 @@ const char* conv2d_variant(const ConvArgs& a) {
                                       {"", "conv_f16x3<1>", "conv_f16x3<2>", "conv_f16x3<3>", "conv_f16x3<4>", "conv_f16x3<5>"}};
     const int tm = cdiv((int64_t)a.N * OH * OW, BM);
     const int pr = effective_precision(a, tm);
-    int nt = pick_nt(a.Cout, tm, pr), ks = 1, ad = 2;
+    int nt = pick_nt(a.Cout, tm, pr, a.lanes), ks = 1, ad = 2;
     if (pr == PREC_BF16X6 && conv2d_wino_eligible(a)) return "conv_wino_bf16x6";
     if (pr == PREC_F32) return names[pr][nt];
     conv2d_split_plan(a, nt, &nt, &ks, &ad);
@@ -800,7 +800,7 @@ void conv2d(ConvArgs a, hipStream_t s) {
         return;
     }
     const int prec = effective_precision(a, p.tiles_m);
-    int nt = pick_nt(a.Cout, p.tiles_m, prec);
+    int nt = pick_nt(a.Cout, p.tiles_m, prec, a.lanes);
     if (prec == PREC_BF16X6 && conv2d_wino_eligible(a)) {
         conv2d_wino(a, s);
         return;

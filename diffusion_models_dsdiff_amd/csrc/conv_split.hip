@@ -233,7 +233,8 @@ void conv2d_split_plan(const ConvArgs& a, int nt_default, int* nt_out, int* ks_o
     const int t32 = cdiv(a.Cout, 32);
     const int KT = a.ks * a.ks * (a.Cin / SBK);
     // only grids that leave CUs idle are re-planned; everything else keeps the measured structure and nt_default
-    if ((int64_t)cdiv((int)M, ad0 * SBM) * cdiv(t32, nt_default) > (ad0 == 1 ? 320 : 160) || KT < 32) return;
+    const int lanes = std::max(1, a.lanes);   // launches of this shape running side by side: each gets 1 / lanes of the chip
+    if ((int64_t)cdiv((int)M, ad0 * SBM) * cdiv(t32, nt_default) * lanes > (ad0 == 1 ? 320 : 160) || KT < 32) return;
     const bool free_structure = a.precision == PREC_BF16X6 && !(a.variant >= 30 && a.variant <= 32);
     double best_t = 1e300;
     for (int ad = 1; ad <= 2; ++ad) {
@@ -251,7 +252,7 @@ void conv2d_split_plan(const ConvArgs& a, int nt_default, int* nt_out, int* ks_o
                 // latency-bound) overlap well; on mid-size M they compete for the matrix pipes and the second one buys
                 // nothing (measured: 8x8 960->960 x16: 480 workgroups 0.098 ms vs 240 0.125; 64x64 640->640 x1: 512
                 // workgroups 0.218 ms vs 256 0.154)
-                const double over = std::max(1.0, (double)blocks * ks / 256.0);
+                const double over = std::max(1.0, (double)blocks * ks * lanes / 256.0);
                 double t = (ad == 1 && M <= 2048 ? std::pow(over, 0.6) : over) * wg;
                 if (ks > 1) t += 9000.0 + (double)ks * M * a.Cout * 4.0 / 2.5e12 * 1.8e9;   // the reduction kernel
                 if (t < best_t * 0.999) {

@@ -43,6 +43,10 @@ struct ConvArgs {
     // coefficients [N][Cin]; the separate apply pass over HBM disappears
     const float* gn_scale = nullptr;
     const float* gn_shift = nullptr;
+    // launches of this shape that run side by side on other HIP streams (the four encoder streams' lanes, net.cpp): the planner
+    // sizes tile width / split-K for 1/lanes of the chip — a grid that would leave three quarters of the CUs idle alone fills them
+    // together, so the wide tap-reuse kernel (with the fused GroupNorm) is the right choice where a lone launch takes narrow tiles
+    int lanes = 1;
 };
 // Output size.  Default padding is ks/2 on every side (the U-Net's convolutions); pad_lo / pad_total describe the VAE's
 // Downsample (ldm/modules/diffusionmodules/model.py:78-83: F.pad (0,1,0,1) then a stride-2 conv with padding 0), i.e. no

@@ -687,6 +687,12 @@ struct Builder {
     bool parallel = false;
     std::vector<std::pair<size_t, size_t>> deferred;
     void begin_parallel() { parallel = true; }
+    // how many launches of the same shape run side by side where the op being built will run (the planner's hint, ConvArgs::lanes)
+    // Only for layers of >= 16384 output pixels: there four launches really run side by side (measured, tools/ab_lanes.py:
+    // batch 1, 128 x 128 level on the wide tap-reuse kernel instead of narrow tiles: 36.9 -> 35.1 ms per step); deeper levels are
+    // short dependent chains of small kernels whose lanes rarely meet in the same layer, and split-K sized for the whole chip
+    // stays the better plan for them (with the hint on every lane level: batch 2 -1.8 % instead of -3.0 %, batch 16 +0.3 %).
+    int plan_lanes(int64_t out_pixels) const { return parallel && hd->use_lanes && out_pixels >= 16384 ? 4 : 1; }
     void set_lane(int l) { lane = l; }
     void end_parallel() {
         parallel = false;
@@ -802,6 +808,11 @@ struct Builder {
         ConvArgs a;
         a.N = x.n; a.H = x.h; a.W = x.w; a.Cin = x.c; a.Cout = cout; a.ks = ks; a.stride = stride; a.ups = ups ? 1 : 0;
         a.pad_lo = pad_lo; a.pad_total = pad_total;
+        {
+            int oh_, ow_;
+            conv_out_hw(a, &oh_, &ow_);
+            a.lanes = plan_lanes((int64_t)x.n * oh_ * ow_);
+        }
         a.w = W(name + ".weight");
         a.bias = bias ? W(name + ".bias") : nullptr;
         const Param& pw = hd->PP(name + ".weight");
@@ -1049,6 +1060,7 @@ struct Builder {
         ConvArgs a;
         a.N = x.n; a.H = x.h; a.W = x.w; a.Cin = x.c; a.Cout = cout; a.ks = 3; a.stride = 1;
         a.precision = PREC_BF16X6;
+        a.lanes = plan_lanes((int64_t)x.n * x.h * x.w);
         a.w_split = this;   // (non-null: only the shape matters here)
         if (hd->use_winograd && conv2d_wino_worthwhile(a)) return false;
         return conv2d_fuses_gn(a);
@@ -2188,7 +2200,7 @@ void dsd::net_plan(dsd_handle* h, int B, int C, int H, int W, int zero_al_l, int
 void dsd::net_launch_ops(dsd_handle* h, hipStream_t s) {
     Plan& p = h->plan;
     bool any_lane = false;
-    if (h->use_lanes)
+    if (h->use_lanes == 1)
         for (signed char l : p.op_lane) any_lane |= l > 0;
     if (!any_lane) {
         for (auto& f : p.ops) f(s);

@@ -123,9 +123,12 @@ int dsd_set_fuse_gn_apply(dsd_handle* h, int on);
  * skip average.  ON by default: from the first encoder block whose input has at most `max_pixels` pixels (batch x H x W;
  * <= 0 keeps the current value, default 16384) the four streams are launched on four HIP streams (the caller's + three of
  * the library's, forked and joined through events inside dsd_forward / dsd_sample, also under hipGraph capture), so that
- * four grids too small to fill 256 CUs share the chip instead of queueing.  Same kernels, same operands: results are
- * bit-identical to on = 0 (every stream in turn on the caller's stream).  The caller sees one stream: work submitted to it
- * after the call is ordered after the join. */
+ * four grids too small to fill 256 CUs share the chip instead of queueing.  The convolutions of those levels are PLANNED for
+ * a quarter of the chip each (tile width / split-K: a layer that would take narrow tiles alone takes the wide tap-reuse kernel
+ * with the fused GroupNorm when its three siblings run beside it), so on = 1 and on = 0 agree to fp32 rounding, not bit for
+ * bit; on = 2 keeps the lanes' plan and launches it on the caller's stream alone — bit-identical to on = 1 (the check that no
+ * dependency between the lanes is missing).  The caller sees one stream: work submitted to it after the call is ordered
+ * after the join. */
 int dsd_set_stream_lanes(dsd_handle* h, int on, int max_pixels);
 /* bf16x6 mode only, OFF by default: 3x3 stride-1 convolutions whose grid fills the chip at least twice (>= 512 workgroups),
  * with an output width that is a power of two <= 256, Cin % 32 == 0 and Cout = 0 or 64 (mod 128), run as Winograd F(2,3)

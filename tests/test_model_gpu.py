@@ -659,10 +659,11 @@ def test_mfma16_shape_full_size(full_model):
 
 
 def test_stream_lanes_are_bit_identical(full_model):
-    """dsd_set_stream_lanes: the small encoder levels of the four streams on four HIP streams (fork / join events) against the
-    sequential order — the same kernels on the same operands, so bit for bit the same, eagerly and under hipGraph replay, at
-    batch 1 (lanes from 128x128 down), batch 3 and with the lane threshold forced to cover every level below the first; five
-    forwards in a row each (a missing dependency shows up as a changing or different result)."""
+    """dsd_set_stream_lanes: the small encoder levels of the four streams on four HIP streams (fork / join events).  The lanes'
+    plan sizes those convolutions for a quarter of the chip each, so it is compared (a) bit for bit with ITSELF launched on one
+    stream (mode 2: a missing dependency between lanes shows up as a different or changing result; five forwards in a row),
+    eagerly and under hipGraph replay, and (b) to fp32 rounding with the sequential plan (mode 0) — at batch 1 (lanes from
+    128x128 down), batch 3 and with the lane threshold forced to cover every level below the first."""
     from diffusion_models_dsdiff_amd.Disc_diff.guided_diffusion.script_util import create_gaussian_diffusion
     from diffusion_models_dsdiff_amd._sched import run_device_loop
     m, _, _ = full_model
@@ -671,23 +672,27 @@ def test_stream_lanes_are_bit_identical(full_model):
         x = randn((B, 4, 256, 256), 600 + B)
         t = (torch.arange(B) * 331 + 5) % 1000
         m.stream_lanes(False)
+        seq = m._run(x.cuda(), t.cuda(), want_feats=False)[0]
+        m.stream_lanes(2, px if px else 16384)
         want = m._run(x.cuda(), t.cuda(), want_feats=False)[0]
-        n_seq = m.plan_info()["launches"]
+        n_plan = m.plan_info()["launches"]
         m.stream_lanes(True, px if px else 16384)
         for _ in range(5):
             got = m._run(x.cuda(), t.cuda(), want_feats=False)[0]
             assert torch.equal(got, want), (B, px)
-        assert m.plan_info()["launches"] == n_seq
+        assert m.plan_info()["launches"] == n_plan
+        assert rel_l2(got, seq) < 2e-6, (B, px, rel_l2(got, seq))
     # inside the sampling loop, eager and replayed from the captured graph
     d = create_gaussian_diffusion(steps=1000, parameterization="v")
     sched = d._schedule(False, 0.0, True)
     shape = (1, 1, 256, 256)
     cond, xT = cond_image_(shape, 611).cuda(), randn(shape, 612).cuda()
     outs = []
-    for lanes, graph in ((False, False), (True, False), (True, True)):
+    for lanes, graph in ((2, False), (True, False), (True, True), (False, False)):
         m.stream_lanes(lanes)
         m.use_graph(graph)
         outs.append(run_device_loop(m, sched, xT, cond, seed=3, first_step=0, n_steps=4))
     m.use_graph(False)
     m.stream_lanes(True)
-    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])      # one stream / four streams / captured graph
+    assert rel_l2(outs[1], outs[3]) < 2e-6                                      # the sequential plan: other tiles, same numbers to rounding
