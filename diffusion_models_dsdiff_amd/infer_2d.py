@@ -76,8 +76,14 @@ def main(argv=None):
     mp = mcfg["model"]["params"]
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-        dev_index = local
+        # rehearsal hooks (never set in production; tests/test_infer_gpu.py): DSD_INFER_BACKEND=gloo + DSD_INFER_SINGLE_DEVICE=1 run
+        # N ranks over gloo on ONE GPU — the sharding, the bucketed broadcast and the gather on real device memory without N GPUs
+        backend = os.environ.get("DSD_INFER_BACKEND", "nccl")
+        dev_index = 0 if os.environ.get("DSD_INFER_SINGLE_DEVICE") else local
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend)
     else:
         dev_index = int(icfg.get("cuda_idx", 0)) if torch.cuda.device_count() > int(icfg.get("cuda_idx", 0)) else 0
     torch.cuda.set_device(dev_index)
