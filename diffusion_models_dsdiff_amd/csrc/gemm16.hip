@@ -91,7 +91,13 @@ struct G16P {
 // M32: the same tile on v_mfma_f32_32x32x16 (a wave's 128 n x 64 m = 4 x 2 accumulator tiles of 32 x 32, four k-steps of 16 per
 // k-tile).  Same matrix-pipe cycles; an MFMA of this shape holds the wave's issue port for 8 of its 32 cycles instead of 8 of 16,
 // which leaves the DMA / ds_read / address instructions of the two waves of a SIMD twice the issue slots.
-template <typename T16, int EPI, int WI = 0, bool M32 = false>
+// LD4: only waves 0-3 — one per SIMD (a workgroup's waves w and w + 4 share a SIMD) — issue the LDS-DMA, each for itself and for
+// its SIMD-mate.  What-if table, round 3: with the DMA flowing but never waited for and the fragments kept in registers the loop
+// still runs 1.44x the time of the bare MFMA loop — a DMA instruction holds its wave's in-order issue until the texture
+// addresser has taken its 64 lanes (16 cycles each, 64 instructions per k-tile and CU), and with all eight waves issuing their
+// pieces right behind the barrier both waves of every SIMD are stuck at the same time.  With one loader per SIMD its mate
+// keeps the matrix pipe busy meanwhile.
+template <typename T16, int EPI, int WI = 0, bool M32 = false, int LD4 = 0>   // LD4: 1 = loaders issue in a burst, 2 = one piece per 4 MFMAs
 __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
     using F = Frag<T16>;
     // [stage][W tile | X tile]; after the k-loop the same memory transposes the output tile (8 waves x 64 rows x 272 B)
@@ -116,34 +122,42 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
     // row + (lane >> 3), physical chunk lane & 7, logical chunk (lane & 7) ^ ((row >> 1) & 7).  Buffer addressing: the
     // per-lane byte offset of a piece is fixed for the whole k-loop (rows beyond M / N get an out-of-range offset: the
     // hardware delivers zeros), the k-tile advances through the SCALAR offset — no vector address arithmetic in the loop.
-    const int srow = wave * 8 + (lane >> 3);                       // + 64 j
-    const int schunk = (lane & 7) ^ ((srow >> 1) & 7);             // ((64 j + srow) >> 1) & 7 == (srow >> 1) & 7
+    constexpr int NV = LD4 != 0 ? 2 : 1;                                  // virtual waves staged by this wave (LD4: itself and wave + 4)
     const int rows_w = min(p.N - bn0, GBN), rows_x = min(p.M - bm0, GBM);
     const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const T16*>(p.w) + (int64_t)bn0 * p.K), 0, (unsigned)rows_w * (unsigned)p.K * 2u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rxb = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(reinterpret_cast<const T16*>(p.x) + (int64_t)bm0 * p.ldx), 0,
         ((unsigned)(rows_x - 1) * (unsigned)p.ldx + (unsigned)p.K) * 2u, 0x00020000);
-    unsigned wvo[4], xvo[4];
+    unsigned wvo[NV][4], xvo[NV][4];
+    int schunk[NV];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = j * 64 + srow;
-        wvo[j] = r < rows_w ? ((unsigned)r * (unsigned)p.K + (unsigned)schunk * 8u) * 2u : 0xFFFFFFF0u;
-        xvo[j] = r < rows_x ? ((unsigned)r * (unsigned)p.ldx + (unsigned)schunk * 8u) * 2u : 0xFFFFFFF0u;
+    for (int v = 0; v < NV; ++v) {
+        const int srow = (wave + 4 * v) * 8 + (lane >> 3);            // + 64 j
+        schunk[v] = (lane & 7) ^ ((srow >> 1) & 7);                   // ((64 j + srow) >> 1) & 7 == (srow >> 1) & 7
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = j * 64 + srow;
+            wvo[v][j] = r < rows_w ? ((unsigned)r * (unsigned)p.K + (unsigned)schunk[v] * 8u) * 2u : 0xFFFFFFF0u;
+            xvo[v][j] = r < rows_x ? ((unsigned)r * (unsigned)p.ldx + (unsigned)schunk[v] * 8u) * 2u : 0xFFFFFFF0u;
+        }
     }
-    // one DMA piece (q = 0..3: W rows 64 q .., q = 4..7: X rows) of the k-tile at k0 into stage `buf`
-    auto stage_piece = [&](int buf, int k0, int q, bool tail) {
-        unsigned char* base = lds + buf * (2 * G_TILE_BYTES) + wave * 1024;
+    // one DMA piece (q = 0..3: W rows 64 q .., q = 4..7: X rows) of virtual wave v of the k-tile at k0 into stage `buf`
+    auto stage_piece = [&](int buf, int k0, int q, int v, bool tail) {
+        unsigned char* base = lds + buf * (2 * G_TILE_BYTES) + (wave + 4 * v) * 1024;
         const int so = __builtin_amdgcn_readfirstlane(k0 * 2);
         // last, partial k-tile: chunks beyond K are zeros (a row's tail would otherwise read its neighbour's head)
-        const bool kok = !tail || k0 + schunk * 8 < p.K;
-        if (q < 4) dma16(rw, base + q * 8192, kok ? wvo[q] : 0xFFFFFFF0u, so);
-        else dma16(rxb, base + G_TILE_BYTES + (q - 4) * 8192, kok ? xvo[q - 4] : 0xFFFFFFF0u, so);
+        const bool kok = !tail || k0 + schunk[v] * 8 < p.K;
+        if (q < 4) dma16(rw, base + q * 8192, kok ? wvo[v][q] : 0xFFFFFFF0u, so);
+        else dma16(rxb, base + G_TILE_BYTES + (q - 4) * 8192, kok ? xvo[v][q - 4] : 0xFFFFFFF0u, so);
     };
     auto stage = [&](int buf, int k0) {
+        if (LD4 != 0 && wave >= 4) return;                                 // (wave-uniform)
         const bool tail = k0 + GBK > p.K;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) stage_piece(buf, k0, q, tail);
+        for (int v = 0; v < NV; ++v)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) stage_piece(buf, k0, q, v, tail);
     };
 
     // ---- fragment read offsets: lane -> row (lane & 15) of a 16-row tile, k chunk 4 ks + (lane >> 4), XOR ((row >> 1) & 7)
@@ -294,15 +308,21 @@ __global__ __launch_bounds__(512, 2) void gemm16_kernel(G16P p) {
         const int buf = t & 1;
         const unsigned char* sb = lds + buf * (2 * G_TILE_BYTES);
         if (!(WI & 2) || t == 0) read_frags(sb, 0, af[0], bf[0]);
-        if (t + 1 < nkt && !(WI & 1)) stage(buf ^ 1, (t + 1) * GBK);
+        if (t + 1 < nkt && !(WI & 1) && LD4 != 2) stage(buf ^ 1, (t + 1) * GBK);
         if (!(WI & 2) || t == 0) read_frags(sb, 1, af[1], bf[1]);   // the second k-step's fragments are on their way while the first one multiplies
+        const bool spread = LD4 == 2 && wave < 4 && t + 1 < nkt;    // (wave-uniform)
+        const bool stail = (t + 1) * GBK + GBK > p.K;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[i][j] = F::mfma(af[ks][i], bf[ks][j], acc[i][j]);
+                if (LD4 == 2) {
+                    if (spread) stage_piece(buf ^ 1, (t + 1) * GBK, i, ks, stail);   // piece i of virtual wave ks: 16 pieces over the tile's 16 MFMA groups
+                }
+            }
             __builtin_amdgcn_s_setprio(0);
         }
         if (WI & 32) {   // (diagnostic) barrier WITHOUT the wait for the DMA: what the exposed latency of the next tile costs
@@ -461,7 +481,10 @@ __global__ __launch_bounds__(256) void ln_modulate16_kernel(const float* __restr
 template <typename T16, int EPI>
 void launch_gemm16(const G16P& p, hipStream_t s) {
     static const bool m32 = getenv("DSD_GEMM16_M32") != nullptr;   // A/B: the 32x32x16 build
-    if (m32)
+    static const bool ld4 = getenv("DSD_GEMM16_LD4") != nullptr;   // A/B: one loader wave per SIMD
+    if (ld4)
+        hipLaunchKernelGGL((gemm16_kernel<T16, EPI, 0, false, 1>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, s, p);
+    else if (m32)
         hipLaunchKernelGGL((gemm16_kernel<T16, EPI, 0, true>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, s, p);
     else
         hipLaunchKernelGGL((gemm16_kernel<T16, EPI>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(512), 0, s, p);
@@ -478,7 +501,10 @@ void launch_gemm16_whatif(const G16P& p, int wi, hipStream_t s) {
         case 15: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 15>), g, b, 0, s, p); break;
         case 16: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 16>), g, b, 0, s, p); break;
         case 32: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 32>), g, b, 0, s, p); break;
+        case 34: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 34>), g, b, 0, s, p); break;
         case 64: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 0, true>), g, b, 0, s, p); break;   // the 32x32x16 build
+        case 128: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 0, false, 1>), g, b, 0, s, p); break;   // one loader wave per SIMD
+        case 129: hipLaunchKernelGGL((gemm16_kernel<_Float16, 0, 0, false, 2>), g, b, 0, s, p); break;   // ... its pieces spread over the MFMA stream
         default: fail("gemm16 what-if %d is not instantiated (0, 1, 2, 3, 4, 7, 15, 16, 32)", wi);
     }
 }

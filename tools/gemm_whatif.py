@@ -8,7 +8,7 @@ L = _lib.lib()
 _lib.require_gpu(0)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 NAMES = {-1: "product", 0: "diag build, nothing removed", 1: "no DMA staging", 2: "fragments read once", 3: "no DMA, fragments once",
-         4: "no epilogue", 16: "output stays in L2", 32: "DMA issued, never waited for", 64: "32x32x16 MFMA build", 7: "MFMA + barrier only", 15: "MFMA only"}
+         4: "no epilogue", 16: "output stays in L2", 32: "DMA issued, never waited for", 34: "DMA never waited for, fragments read once", 64: "32x32x16 MFMA build", 128: "one loader wave per SIMD", 129: "one loader per SIMD, pieces spread", 7: "MFMA + barrier only", 15: "MFMA only"}
 for M, N, K in ((65536, 2304, 768), (65536, 768, 3072), (65536, 3072, 768)):
     fl = 2.0 * M * N * K
     res = {w: [] for w in NAMES}
