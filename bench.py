@@ -78,6 +78,7 @@ def parse_args(argv=None):
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--config", default=os.path.join(ROOT, "configs", "v2-1-cddpm-ds-disc.yaml"))
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-eager-ref", action="store_true", help="skip the oracle-on-this-GPU (PyTorch-ROCm eager) line of the baseline leg")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel hipEvent pass")
     ap.add_argument("--model-channels", type=int, default=None, help="override (debug only; invalidates the metric)")
     ap.add_argument("--precision", default=os.environ.get("DSD_PRECISION", "bf16x6"), choices=list(PASSES),
@@ -187,6 +188,36 @@ def cpu_baseline(unet_params, sd, H, W, budget_s):
            "sample": f"{len(times)} forward(s) of the same U-Net at {H}x{W}, batch 1, fp32, torch-CPU oracle, "
                      f"median {step:.2f} s/step, extrapolated x1000 steps"}
     return rep, x, t, y
+
+
+def eager_gpu_reference(unet_params, sd, B, H, W, dev):
+    """Part of the baseline leg (rank 0, N = 1): the SAME oracle — a restatement of the reference's forward in plain torch ops —
+    run on this box's GPU through PyTorch-ROCm eager (MIOpen / rocBLAS, fp32), i.e. what the reference's own code path costs on
+    an MI355X.  One warm-up and two timed forwards at the headline batch; reported next to the CPU figure, never part of `value`,
+    never on a product path."""
+    from oracle import unet as O
+    cfg = O.UNetConfig.from_params(unet_params)
+    sdg = {k: v.to(dev) for k, v in sd.items()}
+    g = torch.Generator(device=dev).manual_seed(17)
+    x = torch.randn(B, 2, H, W, device=dev, generator=g)
+    t = torch.full((B,), 500, device=dev)
+    with torch.no_grad():
+        O.unet_forward(cfg, sdg, x, t)                # MIOpen picks its kernels on the first call per shape
+        torch.cuda.synchronize(dev)
+        ts = []
+        for _ in range(2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            O.unet_forward(cfg, sdg, x, t)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ts.append(e0.elapsed_time(e1))
+    del sdg
+    torch.cuda.empty_cache()
+    ms = min(ts)
+    return {"ms_per_step": round(ms, 2), "value": round(B / (1000.0 * ms / 1e3), 6), "unit": "slices/s",
+            "what": f"the fp32 oracle (plain torch ops, the reference's own code path) on this GPU through PyTorch-ROCm eager, batch {B}, "
+                    f"{H}x{W}, best of 2 forwards after a warm-up; torch {torch.__version__}"}
 
 
 def cgroup_cpu_quota():
@@ -635,6 +666,11 @@ def run_rank(args):
             # CPU leg: the oracle timed on this host AND used as the checker of the GPU path on the same input, same run
             sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             cpu, x1, t1_, y_cpu = cpu_baseline(leg.unet_params, sd, H, W, args.cpu_seconds)
+            if not args.no_eager_ref and headline_args(args):
+                try:
+                    cpu["torch_eager_same_gpu"] = eager_gpu_reference(leg.unet_params, sd, B, H, W, dev)
+                except Exception as e:          # a side line must never take the headline down
+                    cpu["torch_eager_same_gpu"] = {"error": repr(e)}
             model.set_precision(args.precision)
             y_gpu = model._run(x1.to(dev), t1_.to(dev), want_feats=False)[0].cpu()
             err = float((y_gpu.double() - y_cpu.double()).norm() / y_cpu.double().norm())

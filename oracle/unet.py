@@ -206,7 +206,7 @@ def make_state_dict(cfg: UNetConfig, seed: int) -> "OrderedDict[str, torch.Tenso
 def timestep_embedding(timesteps: torch.Tensor, dim: int, max_period: int = 10000) -> torch.Tensor:
     """ldm/modules/diffusionmodules/util.py:161-181 (repeat_only=False)."""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half).to(timesteps.device)   # (as util.py:174-176: the host's table, moved)
     args = timesteps[:, None].float() * freqs[None]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
