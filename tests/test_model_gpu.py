@@ -263,6 +263,23 @@ def cond_image_(shape, seed):
     return cond_image(shape, seed)
 
 
+@pytest.mark.parametrize("H,W,B", [(128, 256, 2), (256, 128, 1), (64, 256, 3), (192, 192, 1)])
+def test_full_network_other_image_shapes_vs_oracle(full_model, H, W, B):
+    """The 981.5 M network on images that are not 256 x 256 squares: wide, tall (the tap-reuse kernel's tiles are whole image
+    rows: the width decides the path, the height does not), a short wide strip at batch 3, and 192 x 192 — the `image_size` of
+    several of the reference's yamls, whose width sends every large layer to the plain kernel and the separate GroupNorm apply
+    pass.  One oracle forward each, per-sample timesteps; <= 1e-5."""
+    m, cfg, sd = full_model
+    m.set_precision("bf16x6")
+    x = randn((B, 2, H, W), 900 + H + B)
+    t = (torch.arange(B) * 417 + 33) % 1000
+    want = O.unet_forward(cfg, sd, x, t)[0]
+    got = m._run(x.cuda(), t.cuda(), want_feats=False)[0]
+    err = rel_l2(got, want)
+    print(f"full network {B}x{H}x{W}: rel-L2 vs oracle {err:.3e}")
+    assert got.shape == want.shape and err < 1e-5
+
+
 def test_full_size_vs_oracle(full_model):
     """The BASELINE configuration AT ITS OWN SIZE against the CPU oracle (the headline kernels — 256-row tiles, NT = 5,
     XCD-swizzled grids, batch-16 launch shapes — are never selected at 64x64):
