@@ -168,3 +168,43 @@ def test_no_product_kernel_spills_or_uses_scratch():
     # the 8-wave attention kernel must fit two workgroups per CU
     a8 = [k for k in ks if "attention16_dma_kernel" in k["name"] and "Li0ELi8ELi1E" in k["name"]]
     assert a8 and all(k["vgpr"] <= 128 for k in a8), a8
+
+
+def test_unet_spatial_transformer_parameter_table_matches_the_reference_block():
+    """UNetModel(use_spatial_transformer=True): the reference's constructor cannot run here on that branch (it imports omegaconf),
+    so the parameter table of a table-only DSD_BLOCK_UNET handle is pinned part by part: every attention slot must carry exactly
+    the names and shapes of the reference's own SpatialTransformer(64, 4, 16, depth=1, context_dim=[32], use_linear=True)
+    (tests/golden/xattn.npz `spatial_tf_lin_params`, generated from the imported reference), under the slot's prefix; everything
+    else must equal the table of the same network without the transformer, minus its AttentionBlock entries."""
+    import json
+    import numpy as np
+    g = np.load(os.path.join(ROOT, "tests", "golden", "xattn.npz"))
+    ref = {n: tuple(s) for n, s in json.loads(str(g["spatial_tf_lin_params"]))}
+    L = _lib.lib()
+
+    def table(extra):
+        ia = [4, 64, 4, 4, -1, -1, 0, 0, 0, 0, 2, 1, 2, 1, 1, 1, 1] + extra     # model_channels 64, mult (1, 2), attention at ds 1
+        h = C.c_void_p()
+        _lib.check(L.dsd_block_create(_lib.BLOCK_UNET, (C.c_int32 * len(ia))(*ia), len(ia), -1, C.byref(h)))
+        got = {}
+        name, shape, ndim = C.c_char_p(), (C.c_int64 * 4)(), C.c_int()
+        for i in range(L.dsd_param_count(h)):
+            _lib.check(L.dsd_param_info(h, i, C.byref(name), shape, C.byref(ndim)))
+            got[name.value.decode()] = tuple(shape[k] for k in range(ndim.value))
+        L.dsd_destroy(h)
+        return got
+
+    plain, st = table([]), table([1, 1, 32, 1])
+    slots = sorted({n.rsplit(".qkv.weight", 1)[0] for n in plain if n.endswith(".qkv.weight")})
+    assert "input_blocks.1.1" in slots and "middle_block.1" in slots
+    slots64 = [s for s in slots if plain[s + ".norm.weight"] == (64,)]          # 64-channel slots: heads 4 x dim_head 16 = the fixture
+    assert slots64
+    for s in slots64:
+        mine = {n[len(s) + 1:]: shp for n, shp in st.items() if n.startswith(s + ".")}
+        assert mine == ref, s
+    rest_plain = {n: shp for n, shp in plain.items() if not any(n.startswith(s + ".") for s in slots)}
+    rest_st = {n: shp for n, shp in st.items() if not any(n.startswith(s + ".") for s in slots)}
+    assert rest_plain == rest_st
+    for s in slots:                                                              # 128-channel slots: the same sub-names, wider
+        assert f"{s}.transformer_blocks.0.attn2.to_k.weight" in st and st[f"{s}.transformer_blocks.0.attn2.to_k.weight"][1] == 32
+        assert f"{s}.qkv.weight" not in st
