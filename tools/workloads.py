@@ -220,6 +220,46 @@ def latent_path(B, seed=2028):
 
 
 # ------------------------------------------------------------------------------------------------------------ configs[4]
+def dit_eager_proxy(B, dtype=torch.float16):
+    """Timing proxy only: the torch ops a DiT-B/8 forward of the reference issues under autocast (DiT_models.py:101-122,224-243 with
+    timm's Attention / Mlp: fused-SDPA attention, nn.Linear, LayerNorm without affine, adaLN modulate, tanh-GELU, gated residuals),
+    written out with random weights, on this GPU through PyTorch-ROCm eager.  Not the reference (timm is absent here) and not an
+    oracle: it exists to put a number on "the same network through the vendor libraries on the same box"."""
+    import torch.nn.functional as F
+    D, depth, heads, T, p = 768, 12, 12, 4096, 8
+    dev = "cuda"
+    g = torch.Generator(device=dev).manual_seed(3)
+    def w(*s):
+        return (torch.randn(*s, device=dev, generator=g) * 0.02)
+    blocks = [dict(qkv=(w(3 * D, D), w(3 * D)), proj=(w(D, D), w(D)), fc1=(w(4 * D, D), w(4 * D)), fc2=(w(D, 4 * D), w(D)),
+                   ada=(w(6 * D, D), w(6 * D))) for _ in range(depth)]
+    pe, fin = (w(D, 4 * p * p), w(D)), (w(p * p * 8, D), w(p * p * 8))
+    x = torch.randn(B, 4, 512, 512, device=dev, generator=g)
+    c = torch.randn(B, D, device=dev, generator=g)
+
+    def fwd():
+        with torch.autocast("cuda", dtype=dtype):
+            h = F.linear(x.unfold(2, p, p).unfold(3, p, p).permute(0, 2, 3, 1, 4, 5).reshape(B, T, 4 * p * p), *pe)
+            for bl in blocks:
+                m = F.linear(F.silu(c), *bl["ada"]).chunk(6, dim=1)
+                a = F.layer_norm(h, (D,)) * (1 + m[1].unsqueeze(1)) + m[0].unsqueeze(1)
+                q, k, v = F.linear(a, *bl["qkv"]).reshape(B, T, 3, heads, D // heads).permute(2, 0, 3, 1, 4)
+                a = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, T, D)
+                h = h + m[2].unsqueeze(1) * F.linear(a, *bl["proj"])
+                a = F.layer_norm(h, (D,)) * (1 + m[4].unsqueeze(1)) + m[3].unsqueeze(1)
+                h = h + m[5].unsqueeze(1) * F.linear(F.gelu(F.linear(a, *bl["fc1"]), approximate="tanh"), *bl["fc2"])
+            return F.linear(F.layer_norm(h, (D,)), *fin)
+
+    with torch.no_grad():
+        ms, lo, hi, y = timed(fwd, iters=3, warm=2)
+    out = {"ms_per_evaluation": round(ms, 2), "ms_min_max": [round(lo, 2), round(hi, 2)], "finite": bool(torch.isfinite(y.float()).all()),
+           "what": f"the torch ops of a DiT-B/8 forward under torch.autocast({str(dtype)[6:]}) with fused SDPA, random weights, PyTorch-ROCm eager on "
+                   f"this GPU (torch {torch.__version__}); a timing proxy, not the reference and not a parity check"}
+    del blocks, x
+    torch.cuda.empty_cache()
+    return out
+
+
 def dit_step(B, precision="f16", seed=2029):
     from diffusion_models_dsdiff_amd.UNet_DS_Diff.DiT_models import DiT
     dit = fill_(DiT(input_size=512, patch_size=8, in_channels=4, hidden_size=768, depth=12, num_heads=12, num_classes=0), seed)
@@ -240,6 +280,10 @@ def dit_step(B, precision="f16", seed=2029):
            "parity": "unpinned by the reference (timm absent); tests/test_half_gpu.py: 3.2e-5 (fp16) / 2.6e-4 (bf16) vs the fp32 oracle"}
     del dit
     torch.cuda.empty_cache()
+    try:
+        out["torch_eager_same_gpu"] = dit_eager_proxy(B, torch.bfloat16 if precision == "bf16" else torch.float16)
+    except Exception as e:          # a side line must never take the workload down
+        out["torch_eager_same_gpu"] = {"error": repr(e)}
     return out
 
 
