@@ -128,12 +128,18 @@ static bool tr_shape_ok(int ks, int stride, int pad, int OW, int IWg, int OH, in
     return ks == 3 && stride == 1 && pad == 1 && OW == IWg && OH == IHg && ksplit == 1 && !out_nchw &&
            (OW == 32 || OW == 64 || OW == 128 || OW == 256) && ohw % (2 * SBM) == 0 && M % (2 * SBM) == 0 && Cin % SBK == 0;
 }
+// tile widths the tap-reuse kernel is instantiated for: 160 columns (the 320 / 640 / 1280-channel networks) and, round 3, 128
+// columns (128 / 256 / 512 channels: the KL-VAE, narrower U-Nets); DSD_CONV_TR_NT4=0 switches the latter off for A/B runs
+static bool tr_nt_ok(int nt) {
+    static const bool nt4 = !(getenv("DSD_CONV_TR_NT4") && atoi(getenv("DSD_CONV_TR_NT4")) == 0);
+    return nt == 5 || (nt == 4 && nt4);
+}
 static bool conv_tr_ok(const SplitP& p) {
     return tr_enabled() && !p.stamps && tr_shape_ok(p.ks, p.stride, p.pad, p.OW, p.IWg, p.OH, p.IHg, p.ksplit, p.out_nchw, p.ohw, p.M, p.Cin);
 }
 // would conv2d_split(a, nt, ksplit, ad) run the tap-reuse instantiation?  (conv2d_variant: its launches are a kind of their own)
 bool conv2d_split_tr(const ConvArgs& a, int nt, int ksplit, int ad) {
-    if (!(tr_enabled() && !a.stamps && a.precision == PREC_BF16X6 && ad == 2 && nt == 5)) return false;
+    if (!(tr_enabled() && !a.stamps && a.precision == PREC_BF16X6 && ad == 2 && tr_nt_ok(nt))) return false;
     int OH, OW;
     conv_out_hw(a, &OH, &OW);
     const int IHg = a.ups ? a.H * 2 : a.H, IWg = a.ups ? a.W * 2 : a.W;
@@ -160,6 +166,14 @@ static void launch_split(const SplitP& p, int nt, hipStream_t s, int ad) {   // 
         else
             hipLaunchKernelGGL((conv_split_ad_kernel<5, 3, false, 2, false, 0, true>), grid, dim3(256), 0, s, p);
         check_launch("conv_split_ad2_tr");
+        return;
+    }
+    if (ad == 2 && nt == 4 && tr_nt_ok(4) && NP == 3 && !F16 && conv_tr_ok(p)) {
+        if (p.gn_scale)
+            hipLaunchKernelGGL((conv_split_ad_kernel<4, 3, false, 2, false, 0, true, true>), grid, dim3(256), 0, s, p);
+        else
+            hipLaunchKernelGGL((conv_split_ad_kernel<4, 3, false, 2, false, 0, true>), grid, dim3(256), 0, s, p);
+        check_launch("conv_split_ad2_tr4");
         return;
     }
     if (p.gn_scale) fail("conv2d: GroupNorm coefficients given for a problem the tap-reuse kernel does not take (ask conv2d_fuses_gn first)");

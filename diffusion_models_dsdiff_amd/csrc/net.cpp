@@ -1363,16 +1363,33 @@ struct Builder {
     // ---------------------------------------------------------------- KL-VAE blocks (ldm/modules/diffusionmodules/model.py)
     // ResnetBlock.forward with temb = None (:121-149); GroupNorm eps 1e-6 (Normalize :41-42).  x stays owned by the caller.
     Tn vae_res(const std::string& p, const Tn& x, int cout) {
-        Tn a = gn_act(p + ".norm1", x, ACT_SILU, 1e-6f);
-        Tn h = conv(p + ".conv1", a, cout, 3, 1, false, nullptr, nullptr, -1, false, true, nullptr, true);
-        release(a);
-        Tn a2 = gn_act(p + ".norm2", h, ACT_SILU, 1e-6f);
-        release(h);
+        // (as in res_block: where the tap-reuse kernel takes the 3x3 convolution — 128- and 160-column tiles — it applies the
+        // GroupNorm + swish of its input itself and the apply pass disappears)
+        Tn h;
+        if (can_fuse_gn(x, cout)) {
+            GnRef g = gn_prepare(p + ".norm1", x, ACT_SILU, 1e-6f);
+            h = conv(p + ".conv1", x, cout, 3, 1, false, nullptr, nullptr, -1, false, true, nullptr, true, -1, -1, &g);
+            gn_release(g);
+        } else {
+            Tn a = gn_act(p + ".norm1", x, ACT_SILU, 1e-6f);
+            h = conv(p + ".conv1", a, cout, 3, 1, false, nullptr, nullptr, -1, false, true, nullptr, true);
+            release(a);
+        }
         Tn skip = x;
         const bool proj = x.c != cout;
         if (proj) skip = conv(p + ".nin_shortcut", x, cout, 1);
-        Tn out = conv(p + ".conv2", a2, cout, 3, 1, false, nullptr, &skip, -1, false, true, nullptr, true);
-        release(a2);
+        Tn out;
+        if (can_fuse_gn(h, cout)) {
+            GnRef g = gn_prepare(p + ".norm2", h, ACT_SILU, 1e-6f);
+            out = conv(p + ".conv2", h, cout, 3, 1, false, nullptr, &skip, -1, false, true, nullptr, true, -1, -1, &g);
+            gn_release(g);
+            release(h);
+        } else {
+            Tn a2 = gn_act(p + ".norm2", h, ACT_SILU, 1e-6f);
+            release(h);
+            out = conv(p + ".conv2", a2, cout, 3, 1, false, nullptr, &skip, -1, false, true, nullptr, true);
+            release(a2);
+        }
         if (proj) release(skip);
         return out;
     }

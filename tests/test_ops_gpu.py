@@ -372,6 +372,13 @@ TR_CASES = [
     (4, 64, 128, 64, 320),       # non-square
     (2, 64, 64, 32, 320, True),  # nearest x2 folded into the gather: 128 x 128 output from a 64 x 64 input
     (1, 128, 64, 64, 160, True), # the same, non-square, 256 x 128 output
+    # 128-column tiles (round 3: the tap-reuse kernel's second width — 128 / 256 / 512 output channels)
+    # (sizes at which the planner picks the 256-row tile: >= 160 row tiles)
+    (1, 256, 256, 64, 128),      # one column tile
+    (1, 256, 256, 96, 256),      # two column tiles, three channel chunks
+    (4, 128, 128, 128, 256),     # two rows per tile
+    (16, 64, 64, 32, 512),       # four rows per tile, four column tiles
+    (1, 128, 128, 128, 128, True),   # nearest x2 folded in: 256 x 256 output
 ]
 
 
