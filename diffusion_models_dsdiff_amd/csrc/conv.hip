@@ -32,6 +32,7 @@ namespace dsd {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+static constexpr size_t DIRECT_LDS_MAX = 128 * 1024;   // weights of the small-K direct kernel, [K][Cout] fp32 in LDS
 static constexpr int BM = 128;
 static constexpr int BK = 32;
 static constexpr int LDS_STRIDE = 36;
@@ -726,7 +727,7 @@ const char* conv2d_variant(const ConvArgs& a) {
     const int Ktot = a.ks * a.ks * a.Cin;
     if (a.Cin % 4 != 0 || Ktot < 32) {
         if (a.Cout % 4 == 0 && a.Cout / 4 <= 256 && Ktot <= 9 && !a.out_nchw && (!a.emb || a.emb_stride % 4 == 0)) return "conv_direct_cols";
-        return (a.Cout % 4 == 0 && (size_t)Ktot * a.Cout * 4 <= 60 * 1024) ? "conv_direct_lds" : "conv_scalar";
+        return (a.Cout % 4 == 0 && (size_t)Ktot * a.Cout * 4 <= DIRECT_LDS_MAX) ? "conv_direct_lds" : "conv_scalar";
     }
     int OH, OW;
     conv_out_hw(a, &OH, &OW);
@@ -789,7 +790,12 @@ void conv2d(ConvArgs a, hipStream_t s) {
                 hipLaunchKernelGGL((conv_direct_cols_kernel<9, false>), dim3(cdiv(p.M, ppb)), dim3(rpi * W4), 0, s, p, W4, ppb, nullptr, 0);
             }
             check_launch("conv_direct_cols");
-        } else if (a.Cout % 4 == 0 && lds <= 60 * 1024) {
+        } else if (a.Cout % 4 == 0 && lds <= DIRECT_LDS_MAX) {
+            // (beyond the 64 KB default the dynamic LDS size has to be allowed once per process; the latent U-Net's first layer,
+            // 6 -> 320 channels, needs 69 KB and used to fall to the scalar kernel: ~1 ms per evaluation)
+            static const hipError_t lds_attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_direct_lds_kernel),
+                                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)DIRECT_LDS_MAX);
+            DSD_CHECK(lds_attr == hipSuccess, "hipFuncSetAttribute(conv_direct_lds_kernel): %s", hipGetErrorString(lds_attr));
             hipLaunchKernelGGL(conv_direct_lds_kernel, dim3(cdiv(p.M, 64)), dim3(256), lds, s, p);
             check_launch("conv_direct_lds");
         } else {
