@@ -749,7 +749,9 @@ const char* conv2d_variant(const ConvArgs& a) {
     if (n.empty())
         n = std::string(names[pr][nt]) + (ad == 2 ? "" : (ad == 1 ? "/r128" : "/staged")) + (ks > 1 ? "+splitk" : "") + (tr ? "/tr" : "");
     if (tr && a.gn_scale) {   // the instantiation that also applies GroupNorm + SiLU to its input: a kind (kernel symbol) of its own
-        static const std::string gn = n + "+gn";
+        static std::string gnpool[6];   // per tile width (the 128- and the 160-column tile are different kernels)
+        std::string& gn = gnpool[nt];
+        if (gn.empty()) gn = n + "+gn";
         return gn.c_str();
     }
     return n.c_str();
