@@ -90,12 +90,15 @@ template <int ACT>
 __global__ __launch_bounds__(256) void linear_lds_kernel(const float* __restrict__ x, int N, int K, int ldx,
                                                          const float* __restrict__ w, const float* __restrict__ bias, int O,
                                                          float* __restrict__ y, int ldy) {
-    extern __shared__ float xs[];   // [N][K], activated
+    extern __shared__ float xs[];   // [16][K], activated; rows >= N are zeros (the product loop has no row condition)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid * 4; i < N * K; i += 1024) {
+    for (int i = tid * 4; i < 16 * K; i += 1024) {
         const int n = i / K, k = i - n * K;
-        float4 v = *reinterpret_cast<const float4*>(x + (int64_t)n * ldx + k);
-        if (ACT == ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N) {
+            v = *reinterpret_cast<const float4*>(x + (int64_t)n * ldx + k);
+            if (ACT == ACT_SILU) { v.x = silu_f(v.x); v.y = silu_f(v.y); v.z = silu_f(v.z); v.w = silu_f(v.w); }
+        }
         *reinterpret_cast<float4*>(xs + i) = v;
     }
     __syncthreads();
@@ -109,30 +112,28 @@ __global__ __launch_bounds__(256) void linear_lds_kernel(const float* __restrict
         for (int k = lane * 4; k < K; k += 256) {
             const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
 #pragma unroll
-            for (int n = 0; n < 16; ++n)
-                if (n < N) {
-                    const float4 v = *reinterpret_cast<const float4*>(xs + n * K + k);
-                    acc[n] = fmaf(v.x, w4.x, acc[n]);
-                    acc[n] = fmaf(v.y, w4.y, acc[n]);
-                    acc[n] = fmaf(v.z, w4.z, acc[n]);
-                    acc[n] = fmaf(v.w, w4.w, acc[n]);
-                }
+            for (int n = 0; n < 16; ++n) {
+                const float4 v = *reinterpret_cast<const float4*>(xs + n * K + k);
+                acc[n] = fmaf(v.x, w4.x, acc[n]);
+                acc[n] = fmaf(v.y, w4.y, acc[n]);
+                acc[n] = fmaf(v.z, w4.z, acc[n]);
+                acc[n] = fmaf(v.w, w4.w, acc[n]);
+            }
         }
         const float b = bias ? bias[o] : 0.f;
 #pragma unroll
-        for (int n = 0; n < 16; ++n)
-            if (n < N) {
-                float v = acc[n];
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                if (lane == 0) y[(int64_t)n * ldy + o] = v + b;
-            }
+        for (int n = 0; n < 16; ++n) {
+            float v = acc[n];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0 && n < N) y[(int64_t)n * ldy + o] = v + b;
+        }
     }
 }
 
 void linear(const float* x, int N, int K, int ldx, const float* w, const float* bias, int O, int act_in, float* y,
             int ldy, hipStream_t s) {
     if (N == 0 || O == 0) return;
-    const size_t xs_bytes = (size_t)N * K * sizeof(float);
+    const size_t xs_bytes = (size_t)16 * K * sizeof(float);   // (rows beyond N are zero-filled)
     if (N <= 16 && O >= 512 && K % 4 == 0 && ldx % 4 == 0 && xs_bytes <= 96 * 1024) {
         static const hipError_t a0 = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_lds_kernel<ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_lds_kernel<ACT_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
