@@ -249,13 +249,14 @@ class NativeModule(nn.Module):
         return out, runs
 
     def profile_ops(self):
-        """[(kind, ms, flops, bytes)] per op of the plan in launch order, for the last profiled forward."""
+        """[(kind, ms, flops, bytes, layer)] per op of the plan in launch order, for the last profiled forward."""
         L = lib()
-        kind, ms, fl, by = C.c_char_p(), C.c_double(), C.c_double(), C.c_double()
+        kind, ms, fl, by, nm = C.c_char_p(), C.c_double(), C.c_double(), C.c_double(), C.c_char_p()
         out = []
         for i in range(L.dsd_profile_op_count(self._h)):
             check(L.dsd_profile_op_get(self._h, i, C.byref(kind), C.byref(ms), C.byref(fl), C.byref(by)))
-            out.append((kind.value.decode(), ms.value, fl.value, by.value))
+            check(L.dsd_profile_op_name(self._h, i, C.byref(nm)))
+            out.append((kind.value.decode(), ms.value, fl.value, by.value, (nm.value or b"").decode()))
         return out
 
     def __del__(self):

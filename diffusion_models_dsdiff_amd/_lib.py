@@ -26,7 +26,7 @@ PRECISIONS = {"f32": 0, "bf16x3": 1, "bf16x6": 2, "f16x3": 3, "f16": 4, "bf16": 
 EXPORTS = [
     "dsd_last_error", "dsd_device_info", "dsd_create", "dsd_destroy", "dsd_param_count", "dsd_param_info",
     "dsd_set_param", "dsd_set_timestep_freqs", "dsd_set_precision", "dsd_get_precision", "dsd_set_share_zero_streams", "dsd_params_ready", "dsd_plan", "dsd_workspace_bytes", "dsd_device_bytes", "dsd_set_graph", "dsd_graph_stats", "dsd_set_fuse_gn_stats", "dsd_set_fuse_gn_apply", "dsd_set_stream_lanes", "dsd_set_winograd", "dsd_set_slice_ids", "dsd_plan_launches", "dsd_plan_flops",
-    "dsd_profile_enable", "dsd_profile_count", "dsd_profile_get", "dsd_profile_op_count", "dsd_profile_op_get", "dsd_forward", "dsd_sample", "dsd_op_sampler_update", "dsd_sample_dpm", "dsd_op_dpm_step", "dsd_op_dpm_threshold", "dsd_block_create", "dsd_block_forward", "dsd_bench_conv2d", "dsd_bench_conv2d_stamps", "dsd_bench_mfma_peak", "dsd_conv_plan", "dsd_set_conv_mfma16", "dsd_op_conv2d", "dsd_op_conv2d_prec", "dsd_op_gn_silu_conv_out1",
+    "dsd_profile_enable", "dsd_profile_count", "dsd_profile_get", "dsd_profile_op_count", "dsd_profile_op_get", "dsd_profile_op_name", "dsd_forward", "dsd_sample", "dsd_op_sampler_update", "dsd_sample_dpm", "dsd_op_dpm_step", "dsd_op_dpm_threshold", "dsd_block_create", "dsd_block_forward", "dsd_bench_conv2d", "dsd_bench_conv2d_stamps", "dsd_bench_mfma_peak", "dsd_conv_plan", "dsd_set_conv_mfma16", "dsd_op_conv2d", "dsd_op_conv2d_prec", "dsd_op_gn_silu_conv_out1",
     "dsd_op_gaussian_sample", "dsd_op_group_norm", "dsd_op_qkv_attention", "dsd_op_gemm_half", "dsd_bench_gemm_half", "dsd_bench_attention_half", "dsd_op_attention_half", "dsd_op_timestep_embedding", "dsd_op_linear", "dsd_op_philox_normal",
 ]
 
@@ -119,6 +119,7 @@ def lib() -> C.CDLL:
     L.dsd_profile_count.argtypes = [vp]
     L.dsd_op_gn_silu_conv_out1.argtypes = [vp, i32, i32, i32, i32, vp, vp, C.c_float, vp, vp, vp, vp]
     L.dsd_profile_op_count.argtypes = [vp]
+    L.dsd_profile_op_name.argtypes = [vp, i32, C.POINTER(C.c_char_p)]
     L.dsd_profile_op_get.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.dsd_profile_get.argtypes = [vp, i32, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                   C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int)]

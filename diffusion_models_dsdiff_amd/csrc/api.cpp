@@ -367,6 +367,13 @@ int dsd_profile_op_get(dsd_handle* h, int idx, const char** kind, double* ms, do
     DSD_CATCH
 }
 
+int dsd_profile_op_name(dsd_handle* h, int idx, const char** name) {
+    DSD_TRY
+    DSD_CHECK(h && name && idx >= 0 && idx < (int)h->plan.op_name.size(), "op index out of range");
+    *name = h->plan.op_name[idx].c_str();
+    DSD_CATCH
+}
+
 int dsd_block_forward(dsd_handle* h, const float* x, int B, int C, int H, int W, const float* aux, int aux_len,
                       const float* aux2, int aux_len2, float* out, void* stream) {
     DSD_TRY

@@ -134,7 +134,9 @@ void linear(const float* x, int N, int K, int ldx, const float* w, const float* 
             int ldy, hipStream_t s) {
     if (N == 0 || O == 0) return;
     const size_t xs_bytes = (size_t)16 * K * sizeof(float);   // (rows beyond N are zero-filled)
-    if (N <= 16 && O >= 512 && K % 4 == 0 && ldx % 4 == 0 && xs_bytes <= 96 * 1024) {
+    // (9..16 rows: with fewer the wave-per-row kernel wins — it reads each weight row once anyway and does not pay this kernel's
+    // 16 row sums per output; batch 1, the U-Net's conditioning: 79 us there, 412 us here)
+    if (N > 8 && N <= 16 && O >= 512 && K % 4 == 0 && ldx % 4 == 0 && xs_bytes <= 96 * 1024) {
         static const hipError_t a0 = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_lds_kernel<ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_lds_kernel<ACT_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         DSD_CHECK(a0 == hipSuccess && a1 == hipSuccess, "hipFuncSetAttribute(linear_lds_kernel) failed");

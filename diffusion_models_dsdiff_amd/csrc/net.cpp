@@ -783,6 +783,7 @@ struct Builder {
     void op(std::function<void(hipStream_t)> f, int launches = 1, const std::string& kind = "misc", double flops = 0.0,
             double bytes = 0.0) {
         plan.ops.push_back(std::move(f));
+        plan.op_name.push_back(cur_name);
         plan.op_lane.push_back((signed char)(parallel ? lane : -1));
         plan.launches += launches;
         int k = -1;
@@ -796,7 +797,11 @@ struct Builder {
         plan.op_flops.push_back(flops);
         plan.op_bytes.push_back(bytes);
     }
-    float* W(const std::string& n) { return hd->P(n); }
+    std::string cur_name;   // the last parameter looked up: names the ops emitted next (profiles only)
+    float* W(const std::string& n) {
+        cur_name = n;
+        return hd->P(n);
+    }
     bool has(const std::string& n) { return hd->pidx.count(n) != 0; }
 
     // ---- convolution: src is an arena tensor, or (plane >= 0) one of the caller's input planes

@@ -77,6 +77,7 @@ struct Plan {
     bool valid = false;
     std::vector<std::function<void(hipStream_t)>> ops;
     std::vector<signed char> op_lane;   // -1: the caller's stream after joining every lane; 0..3: encoder stream lanes (run concurrently)
+    std::vector<std::string> op_name;   // the last parameter looked up before the op was emitted = the layer it belongs to (dsd_profile_op_name)
     std::vector<int> op_kind;        // index into kind_names
     std::vector<double> op_flops;    // algorithmic FLOPs of the op (0 for memory-bound ops)
     std::vector<double> op_bytes;    // algorithmic bytes (read+write) of the op (0 if not tracked)

@@ -175,6 +175,9 @@ int dsd_profile_get(dsd_handle* h, int idx, const char** kind, double* total_ms,
 /* The same per op of the plan, in launch order, for the last profiled forward (kind = the op's kernel kind). */
 int dsd_profile_op_count(dsd_handle* h);
 int dsd_profile_op_get(dsd_handle* h, int idx, const char** kind, double* ms, double* flops, double* bytes);
+/* The layer op `idx` of the current plan belongs to: the name of the last parameter the graph builder looked up before it
+ * emitted the op ("input_blocks.4.0.in_layers.2.bias", ...; "" for ops in front of the first parameter). */
+int dsd_profile_op_name(dsd_handle* h, int idx, const char** name);
 
 /* ---- sampling loop ----------------------------------------------------------------------- */
 /* Whole-forward hipGraph replay inside dsd_sample / dsd_sample_dpm (OFF by default): the network evaluation of a step is

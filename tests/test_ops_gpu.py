@@ -313,9 +313,9 @@ def test_timestep_embedding(ops):
 
 
 @pytest.mark.parametrize("N,K,O_,act", [(16, 1280, 640, 1), (2, 128, 64, 0), (3, 60, 17, 1), (9, 320, 1280, 0),
-                                        # the LDS-staged kernel (<= 16 rows, >= 512 outputs): DiT-B's adaLN width, a ragged last
-                                        # workgroup (O % 32 != 0), one row, 17 rows (falls back to the wave-per-row kernel)
-                                        (16, 768, 55296, 1), (5, 1280, 1000, 1), (1, 256, 513, 0), (17, 512, 1024, 1)])
+                                        # the LDS-staged kernel (9..16 rows, >= 512 outputs): DiT-B's adaLN width, a ragged last
+                                        # workgroup (O % 32 != 0); 5 and 17 rows take the wave-per-row kernel
+                                        (16, 768, 55296, 1), (9, 1280, 1000, 1), (12, 256, 513, 0), (5, 1280, 1000, 1), (17, 512, 1024, 1)])
 def test_linear(ops, N, K, O_, act):
     g = torch.Generator().manual_seed(K)
     x, w, b = torch.randn(N, K, generator=g), torch.randn(O_, K, generator=g) / K ** 0.5, torch.randn(O_, generator=g)

@@ -34,7 +34,7 @@ def ops_at(B):
     for _ in range(3):
         model(x, t)
         ops = model.profile_ops()
-        acc = [list(o) for o in ops] if acc is None else [[a[0], min(a[1], o[1]), a[2], a[3]] for a, o in zip(acc, ops)]
+        acc = [list(o) for o in ops] if acc is None else [[a[0], min(a[1], o[1]), a[2], a[3], a[4]] for a, o in zip(acc, ops)]
     model.profile(False)
     return acc
 
@@ -42,8 +42,8 @@ def ops_at(B):
 a, r = ops_at(args.batch), ops_at(args.ref_batch)
 if args.dump:
     with open(args.dump, "w") as f:
-        for i, (k, ms, fl, by) in enumerate(a):
-            f.write(f"{i}\t{k}\t{ms * 1e3:.1f}\t{fl:.4g}\t{by:.4g}\n")
+        for i, (k, ms, fl, by, nm) in enumerate(a):
+            f.write(f"{i}\t{k}\t{ms * 1e3:.1f}\t{fl:.4g}\t{by:.4g}\t{nm}\n")
 scale = args.batch / args.ref_batch
 tot_a, tot_r = sum(o[1] for o in a), sum(o[1] for o in r) * scale
 print(f"batch {args.batch}: {tot_a:.2f} ms in {len(a)} ops; batch {args.ref_batch} x {scale:g}: {tot_r:.2f} ms in {len(r)} ops")
@@ -51,7 +51,7 @@ print(f"batch {args.batch}: {tot_a:.2f} ms in {len(a)} ops; batch {args.ref_batc
 
 def grouped(ops, B):
     g_ = collections.OrderedDict()
-    for k, ms, fl, by in ops:
+    for k, ms, fl, by, _nm in ops:
         e = g_.setdefault((k, round(fl / B / 1e6), round(by / B / 1e4)), [0, 0.0])
         e[0] += 1
         e[1] += ms
