@@ -102,31 +102,52 @@ __global__ __launch_bounds__(256) void linear_lds_kernel(const float* __restrict
         *reinterpret_cast<float4*>(xs + i) = v;
     }
     __syncthreads();
-    for (int r = 0; r < 8; ++r) {
-        const int o = blockIdx.x * 32 + wave * 8 + r;
-        if (o >= O) break;      // (wave-uniform)
-        const float* wr = w + (int64_t)o * K;
-        float acc[16];
+    // this wave's 8 output rows x 16 batch rows = 128 partial sums per lane (each lane took every 64th float4 of k)
+    const int o0 = blockIdx.x * 32 + wave * 8;
+    float acc[128];
 #pragma unroll
-        for (int n = 0; n < 16; ++n) acc[n] = 0.f;
-        for (int k = lane * 4; k < K; k += 256) {
-            const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
+    for (int v = 0; v < 128; ++v) acc[v] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        float4 w4[8];
 #pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                const float4 v = *reinterpret_cast<const float4*>(xs + n * K + k);
-                acc[n] = fmaf(v.x, w4.x, acc[n]);
-                acc[n] = fmaf(v.y, w4.y, acc[n]);
-                acc[n] = fmaf(v.z, w4.z, acc[n]);
-                acc[n] = fmaf(v.w, w4.w, acc[n]);
-            }
-        }
-        const float b = bias ? bias[o] : 0.f;
+        for (int r = 0; r < 8; ++r)   // 8 independent 16-byte loads in flight (rows beyond O read row O - 1: never stored)
+            w4[r] = *reinterpret_cast<const float4*>(w + (int64_t)min(o0 + r, O - 1) * K + k);
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
-            float v = acc[n];
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            if (lane == 0 && n < N) y[(int64_t)n * ldy + o] = v + b;
+            const float4 v = *reinterpret_cast<const float4*>(xs + n * K + k);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                float a = acc[r * 16 + n];
+                a = fmaf(v.x, w4[r].x, a);
+                a = fmaf(v.y, w4[r].y, a);
+                a = fmaf(v.z, w4[r].z, a);
+                a = fmaf(v.w, w4[r].w, a);
+                acc[r * 16 + n] = a;
+            }
         }
+    }
+    // reduce-scatter over the 64 lanes: at distance d a lane keeps one half of its values and receives the other lanes' share of
+    // that half — 64 + 32 + ... + 2 = 126 exchanges for 128 sums (an all-reduce per sum would be 768); lane L ends with the two
+    // sums v = 2 L, 2 L + 1, i.e. output row o0 + L / 8, batch rows 2 (L % 8) and 2 (L % 8) + 1
+    int cnt = 128;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const bool up = (lane & d) != 0;
+        cnt >>= 1;
+#pragma unroll
+        for (int jx = 0; jx < 64; ++jx) {
+            if (jx < cnt) {
+                const float lo = acc[jx], hi = acc[jx + cnt];
+                const float recv = __shfl_xor(up ? lo : hi, d);
+                acc[jx] = (up ? hi : lo) + recv;
+            }
+        }
+    }
+    const int o = o0 + (lane >> 3), n0 = 2 * (lane & 7);
+    if (o < O) {
+        const float b = bias ? bias[o] : 0.f;
+        if (n0 < N) y[(int64_t)n0 * ldy + o] = acc[0] + b;
+        if (n0 + 1 < N) y[(int64_t)(n0 + 1) * ldy + o] = acc[1] + b;
     }
 }
 
@@ -134,8 +155,8 @@ void linear(const float* x, int N, int K, int ldx, const float* w, const float* 
             int ldy, hipStream_t s) {
     if (N == 0 || O == 0) return;
     const size_t xs_bytes = (size_t)16 * K * sizeof(float);   // (rows beyond N are zero-filled)
-    // (9..16 rows: with fewer the wave-per-row kernel wins — it reads each weight row once anyway and does not pay this kernel's
-    // 16 row sums per output; batch 1, the U-Net's conditioning: 79 us there, 412 us here)
+    // (9..16 rows: with fewer the wave-per-row kernel wins — it reads each weight row once anyway and does not pay for 16 batch
+    // rows per output; batch 1, the U-Net's conditioning: 79 us there, 412 us with the first version of this kernel)
     if (N > 8 && N <= 16 && O >= 512 && K % 4 == 0 && ldx % 4 == 0 && xs_bytes <= 96 * 1024) {
         static const hipError_t a0 = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_lds_kernel<ACT_NONE>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void*>(linear_lds_kernel<ACT_SILU>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
