@@ -570,6 +570,7 @@ int dsd_conv_plan(int N, int H, int W, int Cin, int Cout, int ks, int stride, in
     if (precision & 16) a.variant = 30;
     if (precision & 32) a.variant = 31;
     if (precision & 64) a.variant = 32;
+    if (precision & 256) a.lanes = 4;   // as inside a stream-lane region: three launches of the same shape run beside this one
     static const int dummy = 0;
     a.w_split = a.precision != PREC_F32 ? &dummy : nullptr;   // only its presence matters to the eligibility test
     conv2d_plan_query(a, structure, nt, ksplit);

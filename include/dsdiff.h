@@ -347,7 +347,8 @@ int dsd_bench_conv2d_stamps(int N, int H, int W, int Cin, int Cout, int warm, in
 int dsd_bench_mfma_peak(int variant, int workgroups_per_cu, float ms_target, int iters, float* avg_ms, double* tflops);
 /* How the library would run a convolution (host-side query, no GPU work): kernel structure (0 both operands staged
  * through LDS, 1 / 2 activations read straight into registers with a 128 / 256-row tile; -1 for the fp32 kernel), N-tile
- * width in 32-column units, split-K factor and the scratch bytes the split needs.  precision as in dsd_op_conv2d_prec. */
+ * width in 32-column units, split-K factor and the scratch bytes the split needs.  precision as in dsd_op_conv2d_prec;
+ * + 256: planned as inside a stream-lane region (dsd_set_stream_lanes), i.e. for a quarter of the chip. */
 /* Process-wide switch (experiment): the dominant convolution kernel (256 x 160 tile, bf16x6, tap reuse,
  * optional fused GroupNorm) with its matrix work issued as v_mfma_f32_16x16x32_bf16 (conv_tr16.hip) instead of
  * v_mfma_f32_32x32x16_bf16.  Same results up to fp32 summation order.  Default: the environment variable

@@ -208,3 +208,23 @@ def test_unet_spatial_transformer_parameter_table_matches_the_reference_block():
     for s in slots:                                                              # 128-channel slots: the same sub-names, wider
         assert f"{s}.transformer_blocks.0.attn2.to_k.weight" in st and st[f"{s}.transformer_blocks.0.attn2.to_k.weight"][1] == 32
         assert f"{s}.qkv.weight" not in st
+
+
+def test_conv_planner_lane_hint():
+    """dsd_conv_plan (host-side, no GPU): a 320 -> 320 3x3 layer on a 128 x 128 map at batch 1 alone takes 96-column tiles (256
+    workgroups fill the chip once); planned for a stream-lane region — three siblings beside it — it takes the 256-row tile
+    with 160 columns, the shape the tap-reuse kernel with the fused GroupNorm runs on.  Layers that fill
+    the chip on their own are planned the same either way."""
+    L = _lib.lib()
+
+    def plan(shape, lanes):
+        st, nt, ks = C.c_int(), C.c_int(), C.c_int()
+        sb = C.c_uint64()
+        _lib.check(L.dsd_conv_plan(*shape, 3, 1, 2 | (256 if lanes else 0), C.byref(st), C.byref(nt), C.byref(ks), C.byref(sb)))
+        return st.value, nt.value, ks.value
+
+    alone, in_lane = plan((1, 128, 128, 320, 320), False), plan((1, 128, 128, 320, 320), True)
+    assert alone[1] < 5 and alone[2] == 1
+    assert in_lane == (2, 5, 1)
+    for shape in ((16, 256, 256, 320, 320), (16, 128, 128, 320, 320), (1, 256, 256, 320, 320)):
+        assert plan(shape, False) == plan(shape, True) == (2, 5, 1), shape
