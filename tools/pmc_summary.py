@@ -34,11 +34,11 @@ def demangle(name):
         n = int(name[i:j])
         parts.append(name[j:j + n])
         i = j + n
-    m = re.match(r"I(DF16_|DF16b)((?:Li\d+E)*)E", name[i:])
+    m = re.match(r"I(DF16_|DF16b)((?:L[ib]\d+E)*)E", name[i:])
     if not parts or not m:
         return name
-    ints = re.findall(r"Li(\d+)E", m.group(2))
-    return "::".join(parts) + "<" + ", ".join(["_Float16" if m.group(1) == "DF16_" else "__bf16"] + ints) + ">"
+    args = [v if t == "i" else ("true" if v != "0" else "false") for t, v in re.findall(r"L([ib])(\d+)E", m.group(2))]
+    return "::".join(parts) + "<" + ", ".join(["_Float16" if m.group(1) == "DF16_" else "__bf16"] + args) + ">"
 
 
 def load(path):
